@@ -1,0 +1,141 @@
+/*
+ * C ABI of libsdag_hip.so -- the MI355X (gfx950) implementation of the SDAG document-attention
+ * prefill and the dense-retrieval inner-product search.
+ *
+ * The reference is pure Python with no native layer: its arithmetic runs inside torch / transformers /
+ * faiss.  Each entry point below therefore cites the reference CALL SITE whose work it replaces (paths
+ * relative to the reference tree).  All functions return 0 on success or a negative SDAG_ERR_* code;
+ * sdag_last_error() returns a thread-local message for the last failure.  No entry point allocates or
+ * frees caller memory.  Every function that launches kernels is asynchronous on the stream it is given
+ * (a hipStream_t passed as void*; NULL = the default stream) and re-entrant per (device, stream).
+ * Device pointers must belong to the current HIP device.
+ */
+#ifndef SDAG_HIP_H
+#define SDAG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDAG_OK 0
+#define SDAG_ERR_ARG (-1)      /* invalid argument (shape, alignment, range) */
+#define SDAG_ERR_CAPACITY (-2) /* caller buffer too small; the needed size is reported */
+#define SDAG_ERR_HIP (-3)      /* a HIP runtime call failed */
+#define SDAG_ERR_DESC (-4)     /* malformed descriptor */
+
+#define SDAG_OUT_BF16 0
+#define SDAG_OUT_F32 1
+
+#define SDAG_ROW_BLOCK 32 /* query rows per descriptor row block */
+#define SDAG_KV_TILE 64   /* keys per descriptor tile */
+
+int sdag_version(void);
+const char* sdag_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Block-sparse descriptor (host side, no GPU work).
+ *
+ * Replaces the L x L boolean mask that build_blocked_causal_mask_full() fills with Python row loops
+ * (src/pipeline/sparse_attention_RAG/SDAG.py:104-127) by a list of (row block, key tile) work items
+ * plus a 32 x 64 bit mask for every partially allowed tile.  Semantics are exactly those of the
+ * reference loops (union of: causal rows below sys_user_len and from qa_start on; per document the
+ * prefix [0, sys_user_len), the causal part of the document and the whole span of each valid
+ * neighbour; rows in no region allow nothing).  Rows that allow nothing are listed as "uniform rows":
+ * after the reference's finfo.min additive mask (SDAG.py:164-173) their softmax is uniform over all L
+ * keys, and the attention kernels reproduce that.
+ *
+ *   spans      2 * n_docs ints (start, end), 0 <= start, end <= L (start >= end: empty document)
+ *   nbr_off    n_docs + 1 offsets into nbr_idx, or NULL for "no neighbours" (the reference's
+ *              doc_neighbors=None, and also its len(doc_neighbors) != num_docs case, SDAG.py:111)
+ *   nbr_idx    neighbour document ids; ids outside [0, n_docs) are skipped (SDAG.py:119-120)
+ *   max_items_per_unit  longest run of key tiles one workgroup walks before the row block is split
+ *              into several units that are merged afterwards; 0 picks a default from the layout
+ *   out        caller buffer of cap_words int32 words (may be NULL to query the size)
+ *   n_words    receives the number of words the descriptor needs
+ * Returns SDAG_ERR_CAPACITY when cap_words is too small (n_words is still set).
+ */
+int sdag_desc_build(int L, int sys_user_len, int n_docs, const int32_t* spans, int qa_start,
+                    const int32_t* nbr_off, const int32_t* nbr_idx, int max_items_per_unit,
+                    int32_t* out, int64_t cap_words, int64_t* n_words);
+
+/* Same descriptor from an arbitrary dense mask (uint8 [L, L] on the host, nonzero = may attend), for
+ * callers of generate_with_custom_mask() that bring their own prompt_mask (SDAG.py:130-136,167-171). */
+int sdag_desc_from_dense(const uint8_t* mask, int L, int max_items_per_unit, int32_t* out,
+                         int64_t cap_words, int64_t* n_words);
+
+/* Number of (row, column) pairs the descriptor allows, not counting uniform rows; n_uniform_rows may
+ * be NULL.  Used for FLOP accounting. */
+int sdag_desc_stats(const int32_t* desc_host, int64_t* allowed_pairs, int32_t* n_uniform_rows,
+                    int32_t* n_units, int32_t* n_items, int32_t* n_partial_tiles);
+
+/* Expand a descriptor (device copy) into a dense uint8 [L, L] mask on the device: 1 = may attend.
+ * This is what build_blocked_causal_mask_full() returns (SDAG.py:105,127) and is how the descriptor
+ * is proven bit-identical to the reference mask. */
+int sdag_mask_materialize(const int32_t* desc_host, const int32_t* desc_dev, uint8_t* out_dev,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Masked attention prefill: O = softmax(Q K^T * scale + M) V with grouped-query heads, M given by the
+ * descriptor.  Replaces the attention the reference reaches through
+ *   model(input_ids=input_ids, attention_mask=attn[1,1,L,L], use_cache=True)   (SDAG.py:176)
+ * i.e. transformers' LlamaAttention -> attention_interface(query[B,Hq,L,D], key[B,Hkv,L,D],
+ * value[B,Hkv,L,D], attention_mask, scaling) -> output [B,L,Hq,D].
+ *
+ * q, k, v: bf16, head_dim D = 128 contiguous; element strides for batch / head / row are passed so
+ * the transposed views transformers produces need no copy (all strides multiples of 8 elements, base
+ * pointers 16-byte aligned).  o: [B, L, Hq, D] with element strides o_sb / o_sl / o_sh, bf16 or fp32
+ * (out_dtype).  The same descriptor applies to every batch element.  Hq must be a multiple of Hkv.
+ * workspace: device scratch of at least sdag_attn_workspace_bytes() bytes (may be NULL when that is 0).
+ */
+int64_t sdag_attn_workspace_bytes(const int32_t* desc_host, int B, int Hq, int Hkv);
+
+int sdag_attn_fwd(const void* q, const void* k, const void* v, void* o,
+                  int64_t q_sb, int64_t q_sh, int64_t q_sl,
+                  int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                  int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                  int64_t o_sb, int64_t o_sl, int64_t o_sh,
+                  int B, int Hq, int Hkv, int L, int D, float scale,
+                  const int32_t* desc_host, const int32_t* desc_dev,
+                  void* workspace, int64_t workspace_bytes, int out_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Exact inner-product search.  Replaces  scores, indices = index.search(q, top_k)
+ * (src/pipeline/retrieval/dense.py:82-84; the arithmetic of the reference is inside faiss).
+ *
+ *   score(q, c) = fp32 FMA chain over the dimensions in order, starting from +0
+ *   order       = (score descending, id ascending); NaN scores are never returned
+ *   fill        = (score -FLT_MAX, id -1) when fewer than k rows exist
+ *
+ * Q [nq, d] fp32 row-major (device), C [N, d] fp32 row-major (device), d a multiple of 32, 1 <= k <= 64.
+ * out_s [nq, k] fp32 and out_i [nq, k] int64 on the device; ids are id_base + row.
+ * workspace: at least sdag_dense_workspace_bytes(nq, N, d, k) bytes of device scratch.
+ */
+int64_t sdag_dense_workspace_bytes(int nq, int64_t N, int d, int k);
+
+int sdag_dense_topk(const float* Q, int nq, const float* C, int64_t N, int d, int k,
+                    float* out_s, int64_t* out_i, int64_t id_base,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Merge n_parts partial result lists (each [nq, k], as written by sdag_dense_topk on one corpus
+ * shard, e.g. after an all-gather) into the global best k per query, same ordering rule.
+ * in_s [n_parts, nq, k], in_i [n_parts, nq, k] on the device; entries with id < 0 are fill. */
+int sdag_topk_merge(const float* in_s, const int64_t* in_i, int n_parts, int nq, int k,
+                    float* out_s, int64_t* out_i, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small similarity ops on unit-norm fp32 embeddings.
+ *
+ * sdag_gram: sims = E E^T for E [n, d] (device) -> sims [n, n]; replaces np.matmul(emb, emb.T) in
+ * compute_doc_knn_for_docs (SDAG.py:50).  sdag_centroid_sims: centroid = mean of R [nr, d] rows,
+ * sims[j] = <Cand[j], centroid>; replaces malicious_selection.py:89-95,117-123.  Both use the same
+ * dimension-ordered fp32 FMA chain as the search. */
+int sdag_gram(const float* E, int n, int d, float* sims, void* stream);
+int sdag_centroid_sims(const float* R, int nr, const float* Cand, int nc, int d, float* centroid,
+                       float* sims, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,544 @@
+// SDAG block-sparse attention prefill for gfx950 (MI355X), bf16 in, fp32 softmax/accumulate.
+//
+// Replaces the dense-masked attention the reference reaches from
+//   model(input_ids=input_ids, attention_mask=attn[1,1,L,L], use_cache=True)
+// (src/pipeline/sparse_attention_RAG/SDAG.py:176; transformers' LlamaAttention / eager_attention_forward:
+// repeat_kv, Q K^T * scaling + mask, fp32 softmax, P V, output [B, L, Hq, D]).
+//
+// Work decomposition
+//   One workgroup (4 waves) = one descriptor unit: a 32-row query block x a run of 64-key tiles, for ONE
+//   key/value head.  The four waves take four query heads that share that key/value head (grouped-query
+//   attention), so one K/V tile staged in LDS feeds four heads, and all four waves see the same mask.
+//   blockIdx % (Hkv * head_groups) selects the key/value head, so with 8 KV heads every block that reads a
+//   given head's K/V runs on the same XCD and shares that XCD's L2.
+// Per tile, per wave
+//   S^T = K Q^T   (16 x v_mfma_f32_32x32x16_bf16; keys in the accumulator rows, the query on the lane, so the
+//                  softmax row statistics are lane-local plus one exchange between the two 32-lane halves)
+//   online softmax in fp32 registers, masked by the tile's 32 x 64 bit mask when it has one
+//   O^T += V^T P^T (16 MFMAs; the S^T accumulators, converted to bf16, are directly the B operand; V^T comes
+//                  from LDS through ds_read_b64_tr_b16)
+// K and V tiles are register-staged (global_load_dwordx4 -> ds_write_b128) into an XOR-swizzled image that is
+// conflict-free for both the row reads of K and the transposed reads of V, double buffered, one barrier a tile.
+// Row blocks with long tile runs are split into several units; their partial (O, m, l) go to a workspace and a
+// second kernel merges them.  Rows that allow nothing get mean(V) (uniform softmax over all L keys), from
+// per-chunk column sums that extra blocks of the main launch compute.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace sdag {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+constexpr int D = 128;            // head dim
+constexpr int RB = 32;            // query rows per workgroup (one MFMA tile)
+constexpr int KT = 64;            // keys per tile
+constexpr int TILE_BYTES = KT * D * 2;
+constexpr int VSUM_CHUNKS = 32;   // column-sum partials per (batch, kv head)
+
+struct AttnParams {
+    const unsigned short* q;
+    const unsigned short* k;
+    const unsigned short* v;
+    void* o;
+    int64_t q_sb, q_sh, q_sl;
+    int64_t k_sb, k_sh, k_sl;
+    int64_t v_sb, v_sh, v_sl;
+    int64_t o_sb, o_sl, o_sh;
+    int B, Hq, Hkv, L;
+    int G;        // query heads per kv head
+    int HG;       // groups of 4 query heads per kv head
+    int n_units;
+    int n_main_blocks;
+    int out_f32;
+    float c;      // scale * log2(e)
+    const int32_t* desc;
+    float* part_o;   // [slot][B][Hq][32][128]
+    float* part_ml;  // [slot][B][Hq][32][2]
+    float* vsum;     // [B][Hkv][VSUM_CHUNKS][128]
+};
+
+// Byte offset of 16-byte chunk `ch` of row `row` inside a [64][128] bf16 tile image.  The XOR makes both
+// ds_read_b128 row reads (32 lanes = 32 rows, one chunk column) and ds_read_b64_tr_b16 4-row block reads
+// conflict-free.
+__device__ __forceinline__ int tile_off(int row, int ch) {
+    return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ void vsum_block(const AttnParams& p, int vb, unsigned char* smem) {
+    // vb -> (b, kvh, chunk); 256 threads: 32 column quads x 8 row lanes.
+    const int chunk = vb % VSUM_CHUNKS;
+    const int kvh = (vb / VSUM_CHUNKS) % p.Hkv;
+    const int b = vb / (VSUM_CHUNKS * p.Hkv);
+    const int rows_per = (p.L + VSUM_CHUNKS - 1) / VSUM_CHUNKS;
+    const int r0 = chunk * rows_per, r1 = min(p.L, r0 + rows_per);
+    const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const unsigned short* base = p.v + b * p.v_sb + kvh * p.v_sh + cq * 4;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int r = r0 + rl; r < r1; r += 8) {
+        const uint2 w = *reinterpret_cast<const uint2*>(base + (int64_t)r * p.v_sl);
+        s0 += __uint_as_float(w.x << 16);
+        s1 += __uint_as_float(w.x & 0xffff0000u);
+        s2 += __uint_as_float(w.y << 16);
+        s3 += __uint_as_float(w.y & 0xffff0000u);
+    }
+    float* red = reinterpret_cast<float*>(smem);  // [8][128]
+    red[rl * 128 + cq * 4 + 0] = s0;
+    red[rl * 128 + cq * 4 + 1] = s1;
+    red[rl * 128 + cq * 4 + 2] = s2;
+    red[rl * 128 + cq * 4 + 3] = s3;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i * 128 + threadIdx.x];
+        p.vsum[((int64_t)(b * p.Hkv + kvh) * VSUM_CHUNKS + chunk) * 128 + threadIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];  // K0 K1 V0 V1
+
+    int bid = blockIdx.x;
+    if (bid >= p.n_main_blocks) {
+        vsum_block(p, bid - p.n_main_blocks, smem);
+        return;
+    }
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_hslots = p.Hkv * p.HG;
+    const int hslot = bid % n_hslots;
+    const int rest = bid / n_hslots;
+    const int unit = rest % p.n_units;
+    const int b = rest / p.n_units;
+    const int kvh = hslot % p.Hkv;
+    const int hg = hslot / p.Hkv;
+    const int hin = hg * 4 + wave;
+    const bool head_ok = hin < p.G;
+    const int hq = kvh * p.G + (head_ok ? hin : p.G - 1);
+
+    const int32_t* desc = p.desc;
+    const int32_t* up = desc + desc[H_OFF_UNITS] + unit * 4;
+    const int rb = up[0], it_begin = up[1], it_end = up[2], slot = up[3];
+    const int32_t* items = desc + desc[H_OFF_ITEMS];
+    const uint64_t* masks = reinterpret_cast<const uint64_t*>(desc + desc[H_OFF_MASKS]);
+    const unsigned uniform_bits = (unsigned)desc[desc[H_OFF_RBINFO] + rb * 2];
+
+    const int r = lane & 31;  // query row inside the block (S^T / O^T column)
+    const int h = lane >> 5;
+    const int row = rb * RB + r;
+    const int row_ld = min(row, p.L - 1);
+
+    // ---- Q fragments: B operand of S^T = K Q^T; lane (r, h) holds Q[row][16 ks + 8 h .. +7].
+    bf16x8 qf[8];
+    {
+        const unsigned short* qp = p.q + b * p.q_sb + hq * p.q_sh + (int64_t)row_ld * p.q_sl + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    }
+
+    // ---- staging geometry: thread covers chunk (tid & 15) of rows (tid >> 4) + 16 i, i = 0..3.
+    const int st_row = tid >> 4, st_ch = tid & 15;
+    const int st_off = tile_off(st_row, st_ch);  // + 16 * 256 * i for the other rows (swizzle term unchanged)
+    const unsigned short* kbase = p.k + b * p.k_sb + kvh * p.k_sh + st_ch * 8;
+    const unsigned short* vbase = p.v + b * p.v_sb + kvh * p.v_sh + st_ch * 8;
+    u32x4 kreg[4], vreg[4];
+
+    auto stage_load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kr = min(kt * KT + st_row + 16 * i, p.L - 1);
+            kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)kr * p.k_sl);
+            vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)kr * p.v_sl);
+        }
+    };
+    auto stage_store = [&](int buf) {
+        unsigned char* kd = smem + buf * TILE_BYTES + st_off;
+        unsigned char* vd = smem + (2 + buf) * TILE_BYTES + st_off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(kd + i * 16 * 256) = kreg[i];
+            *reinterpret_cast<u32x4*>(vd + i * 16 * 256) = vreg[i];
+        }
+    };
+
+    // ---- K read geometry: row kb*32 + r, chunk (2 ks + h) ^ f(r)
+    const int kf = ((r & 3) << 2) | ((r >> 2) & 3);
+    const int k_row_off = r * 256;
+    // ---- V transposed-read geometry (ds_read_b64_tr_b16 delivers, per 16-lane group, a 4-key x 16-column
+    // block column-major: lane i of the group supplies the address of key (i >> 2), columns 4 (i & 3) .. +3,
+    // and receives column i).
+    const int g16 = (lane >> 4) & 1, li = lane & 15, vq = li >> 2, vp = li & 3;
+    const int cl = 2 * g16 + (vp >> 1);
+    int v_off[4][2];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+            v_off[db][hf] = (4 * h + vq) * 256 + (((((db ^ vq) << 2) | (cl ^ (2 * hf + h)))) << 4) + 8 * (vp & 1);
+
+    f32x16 oacc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c = p.c;
+
+    stage_load(items[it_begin * 2]);
+    stage_store(0);
+    __syncthreads();
+
+    int cur = 0;
+    for (int it = it_begin; it < it_end; ++it) {
+        const int mask_idx = items[it * 2 + 1];
+        const bool has_next = it + 1 < it_end;
+        if (has_next) stage_load(items[(it + 1) * 2]);
+
+        const unsigned char* kb_lds = smem + cur * TILE_BYTES;
+        const unsigned char* vb_lds = smem + (2 + cur) * TILE_BYTES;
+
+        // ---- S^T = K Q^T : two 32-key blocks
+        f32x16 s0, s1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int ch = ((2 * ks + h) ^ kf) << 4;
+            const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kb_lds + k_row_off + ch);
+            const bf16x8 kb2 = *reinterpret_cast<const bf16x8*>(kb_lds + 32 * 256 + k_row_off + ch);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2, qf[ks], s1, 0, 0, 0);
+        }
+
+        // ---- mask: accumulator register i of block kb is key 32 kb + (i & 3) + 8 (i >> 2) + 4 h
+        if (mask_idx >= 0) {
+            const uint64_t mrow = masks[(int64_t)mask_idx * RB + r];
+            const unsigned lo = (unsigned)mrow >> (4 * h);
+            const unsigned hi = (unsigned)(mrow >> 32) >> (4 * h);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int bit = (i & 3) + 8 * (i >> 2);
+                s0[i] = ((lo >> bit) & 1u) ? s0[i] : -INFINITY;
+                s1[i] = ((hi >> bit) & 1u) ? s1[i] : -INFINITY;
+            }
+        }
+
+        // ---- online softmax (per query = per lane, halves combined by one exchange)
+        float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[i], s1[i]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = fast_exp2((m_run - m_safe) * c);
+        const float msc = m_safe * c;
+        float rs = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            s0[i] = fast_exp2(__builtin_fmaf(s0[i], c, -msc));
+            s1[i] = fast_exp2(__builtin_fmaf(s1[i], c, -msc));
+            rs += s0[i] + s1[i];
+        }
+        rs += __shfl_xor(rs, 32);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
+        }
+
+        // ---- P^T fragments: registers 8 s .. 8 s + 7 of block kb are k-step (kb, s) of the B operand
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            pf[0][0][j] = (__bf16)s0[j];
+            pf[0][1][j] = (__bf16)s0[8 + j];
+            pf[1][0][j] = (__bf16)s1[j];
+            pf[1][1][j] = (__bf16)s1[8 + j];
+        }
+
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int rbase = (32 * kb + 16 * s) * 256;
+                    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(vb_lds + rbase + v_off[db][0]));
+                    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(vb_lds + rbase + 8 * 256 + v_off[db][1]));
+                    union { s16x4 hlf[2]; bf16x8 full; } va;
+                    va.hlf[0] = a0;
+                    va.hlf[1] = a1;
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.full, pf[kb][s], oacc[db], 0, 0, 0);
+                }
+            }
+        }
+
+        if (has_next) stage_store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (!head_ok) return;
+
+    // ---- epilogue.  O^T register i of block db is column d = 32 db + (i & 3) + 8 (i >> 2) + 4 h of row `row`.
+    if (slot >= 0) {
+        const int64_t prow = (((int64_t)slot * p.B + b) * p.Hq + hq) * RB + r;
+        float* po = p.part_o + prow * D;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 w = {oacc[db][4 * g], oacc[db][4 * g + 1], oacc[db][4 * g + 2], oacc[db][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(po + 32 * db + 8 * g + 4 * h) = w;
+            }
+        if (h == 0) {
+            p.part_ml[prow * 2] = m_run;
+            p.part_ml[prow * 2 + 1] = l_run;
+        }
+        return;
+    }
+    if (row >= p.L || ((uniform_bits >> r) & 1u) || !(l_run > 0.f)) return;
+    const float inv = 1.0f / l_run;
+    const int64_t obase = b * p.o_sb + (int64_t)row * p.o_sl + hq * p.o_sh;
+    if (p.out_f32) {
+        float* op = reinterpret_cast<float*>(p.o) + obase;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 w = {oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv, oacc[db][4 * g + 2] * inv,
+                           oacc[db][4 * g + 3] * inv};
+                *reinterpret_cast<f32x4*>(op + 32 * db + 8 * g + 4 * h) = w;
+            }
+    } else {
+        unsigned short* op = reinterpret_cast<unsigned short*>(p.o) + obase;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 w = {(__bf16)(oacc[db][4 * g] * inv), (__bf16)(oacc[db][4 * g + 1] * inv),
+                            (__bf16)(oacc[db][4 * g + 2] * inv), (__bf16)(oacc[db][4 * g + 3] * inv)};
+                *reinterpret_cast<bf16x4*>(op + 32 * db + 8 * g + 4 * h) = w;
+            }
+    }
+}
+
+// Merge the partial results of split row blocks, and write mean(V) into rows that allow nothing.
+// grid: (n_split * B * Hq) blocks of 256 threads for the merge, then ceil(n_uniform * B * Hq / 8) blocks for
+// the uniform rows (8 (row, head) pairs per block, 32 threads x 4 columns each).
+__global__ __launch_bounds__(256) void sdag_attn_combine(const AttnParams p, int n_merge_blocks) {
+    const int32_t* desc = p.desc;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < n_merge_blocks) {
+        const int hq = blockIdx.x % p.Hq;
+        const int rest = blockIdx.x / p.Hq;
+        const int b = rest % p.B;
+        const int e = rest / p.B;
+        const int32_t* sp = desc + desc[H_OFF_SPLIT] + e * 4;
+        const int rb = sp[0], first = sp[1], n = sp[2];
+        // thread -> row (tid >> 3), 16 columns starting at (tid & 7) * 16
+        const int r = tid >> 3, c0 = (tid & 7) * 16;
+        const int row = rb * RB + r;
+        if (row >= p.L) return;
+        float mmax = -INFINITY;
+        for (int s = 0; s < n; ++s) {
+            const int64_t prow = (((int64_t)(first + s) * p.B + b) * p.Hq + hq) * RB + r;
+            mmax = fmaxf(mmax, p.part_ml[prow * 2]);
+        }
+        if (mmax == -INFINITY) return;  // uniform row: handled below
+        float acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        float den = 0.f;
+        for (int s = 0; s < n; ++s) {
+            const int64_t prow = (((int64_t)(first + s) * p.B + b) * p.Hq + hq) * RB + r;
+            const float ms = p.part_ml[prow * 2];
+            const float w = fast_exp2((ms - mmax) * p.c);  // ms = -inf -> 0
+            den += w * p.part_ml[prow * 2 + 1];
+            const f32x4* po = reinterpret_cast<const f32x4*>(p.part_o + prow * D + c0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 x = po[i];
+                acc[4 * i] += w * x[0];
+                acc[4 * i + 1] += w * x[1];
+                acc[4 * i + 2] += w * x[2];
+                acc[4 * i + 3] += w * x[3];
+            }
+        }
+        const float inv = 1.0f / den;
+        const int64_t obase = b * p.o_sb + (int64_t)row * p.o_sl + hq * p.o_sh + c0;
+        if (p.out_f32) {
+            float* op = reinterpret_cast<float*>(p.o) + obase;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 w = {acc[4 * i] * inv, acc[4 * i + 1] * inv, acc[4 * i + 2] * inv, acc[4 * i + 3] * inv};
+                reinterpret_cast<f32x4*>(op)[i] = w;
+            }
+        } else {
+            unsigned short* op = reinterpret_cast<unsigned short*>(p.o) + obase;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                bf16x8 w;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[j] = (__bf16)(acc[8 * i + j] * inv);
+                reinterpret_cast<bf16x8*>(op)[i] = w;
+            }
+        }
+        return;
+    }
+    // ---- uniform rows: softmax over all-equal scores = 1/L on every key -> mean of V over all L keys
+    const int n_uni = desc[H_NUNIFORM];
+    const int64_t pair = (int64_t)(blockIdx.x - n_merge_blocks) * 8 + (tid >> 5);
+    const int64_t n_pairs = (int64_t)n_uni * p.B * p.Hq;
+    if (pair >= n_pairs) return;
+    const int hq = pair % p.Hq;
+    const int64_t rest = pair / p.Hq;
+    const int b = rest % p.B;
+    const int ui = rest / p.B;
+    const int row = desc[desc[H_OFF_UNIFORM] + ui];
+    const int kvh = hq / p.G;
+    const int c0 = (tid & 31) * 4;
+    const float* vs = p.vsum + (int64_t)(b * p.Hkv + kvh) * VSUM_CHUNKS * 128 + c0;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < VSUM_CHUNKS; ++ch) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(vs + ch * 128);
+        t += x;
+    }
+    const float invL = 1.0f / (float)p.L;
+    const int64_t obase = b * p.o_sb + (int64_t)row * p.o_sl + hq * p.o_sh + c0;
+    if (p.out_f32) {
+        f32x4 w = {t[0] * invL, t[1] * invL, t[2] * invL, t[3] * invL};
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.o) + obase) = w;
+    } else {
+        bf16x4 w = {(__bf16)(t[0] * invL), (__bf16)(t[1] * invL), (__bf16)(t[2] * invL), (__bf16)(t[3] * invL)};
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<unsigned short*>(p.o) + obase) = w;
+    }
+}
+
+// Dense uint8 [L, L] image of a descriptor: one block per row block; zero the 32 rows, then paint every item.
+__global__ __launch_bounds__(256) void sdag_mask_expand(const int32_t* desc, unsigned char* out) {
+    const int L = desc[H_L];
+    const int rb = blockIdx.x;
+    const int r0 = rb * RB, rows = min(RB, L - r0);
+    const int tid = threadIdx.x;
+    for (int64_t i = tid; i < (int64_t)rows * L; i += 256) out[(int64_t)r0 * L + i] = 0;
+    __syncthreads();
+    const int n_units = desc[H_NUNITS];
+    const int32_t* units = desc + desc[H_OFF_UNITS];
+    const int32_t* items = desc + desc[H_OFF_ITEMS];
+    const uint64_t* masks = reinterpret_cast<const uint64_t*>(desc + desc[H_OFF_MASKS]);
+    for (int u = 0; u < n_units; ++u) {
+        if (units[u * 4] != rb) continue;
+        for (int it = units[u * 4 + 1]; it < units[u * 4 + 2]; ++it) {
+            const int kt = items[it * 2], mi = items[it * 2 + 1];
+            for (int e = tid; e < RB * KT; e += 256) {
+                const int r = e >> 6, cidx = e & 63;
+                const int col = kt * KT + cidx;
+                if (r >= rows || col >= L) continue;
+                const bool on = mi < 0 ? true : ((masks[(int64_t)mi * RB + r] >> cidx) & 1ull);
+                if (on) out[(int64_t)(r0 + r) * L + col] = 1;
+            }
+        }
+    }
+}
+
+}  // namespace
+}  // namespace sdag
+
+using namespace sdag;
+
+extern "C" int64_t sdag_attn_workspace_bytes(const int32_t* d, int B, int Hq, int Hkv) {
+    if (!desc_ok(d) || B <= 0 || Hq <= 0 || Hkv <= 0) return -1;
+    int64_t bytes = 0;
+    const int64_t n_slots = d[H_NSLOTS];
+    bytes += n_slots * B * Hq * RB * (D + 2) * (int64_t)sizeof(float);
+    if (d[H_NUNIFORM] > 0) bytes += (int64_t)B * Hkv * VSUM_CHUNKS * 128 * sizeof(float);
+    return (bytes + 255) & ~255ll;
+}
+
+extern "C" int sdag_attn_fwd(const void* q, const void* k, const void* v, void* o,
+                             int64_t q_sb, int64_t q_sh, int64_t q_sl,
+                             int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                             int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                             int64_t o_sb, int64_t o_sl, int64_t o_sh,
+                             int B, int Hq, int Hkv, int L, int Dh, float scale,
+                             const int32_t* desc_host, const int32_t* desc_dev,
+                             void* workspace, int64_t workspace_bytes, int out_dtype, void* stream) {
+    if (Dh != D) return fail(SDAG_ERR_ARG, "head_dim %d not supported (only 128)", Dh);
+    if (!desc_ok(desc_host)) return fail(SDAG_ERR_DESC, "desc_host is not a descriptor");
+    if (!desc_dev) return fail(SDAG_ERR_ARG, "desc_dev is NULL");
+    if (desc_host[H_L] != L) return fail(SDAG_ERR_DESC, "descriptor is for L=%d, call has L=%d", desc_host[H_L], L);
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || L <= 0 || Hq % Hkv) return fail(SDAG_ERR_ARG, "bad B/Hq/Hkv/L");
+    if (!(scale > 0.f)) return fail(SDAG_ERR_ARG, "scale must be positive");
+    if (out_dtype != SDAG_OUT_BF16 && out_dtype != SDAG_OUT_F32) return fail(SDAG_ERR_ARG, "bad out_dtype");
+    if (!q || !k || !v || !o) return fail(SDAG_ERR_ARG, "NULL tensor pointer");
+    const int64_t strides[] = {q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sl, o_sh};
+    for (int64_t s : strides)
+        if (s < 0 || (s & 7)) return fail(SDAG_ERR_ARG, "strides must be non-negative multiples of 8 elements");
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return fail(SDAG_ERR_ARG, "tensor pointers must be 16-byte aligned");
+    const int64_t need = sdag_attn_workspace_bytes(desc_host, B, Hq, Hkv);
+    if (need > 0 && (!workspace || workspace_bytes < need)) return fail(SDAG_ERR_CAPACITY, "workspace needs %lld bytes", (long long)need);
+
+    AttnParams p;
+    p.q = (const unsigned short*)q; p.k = (const unsigned short*)k; p.v = (const unsigned short*)v; p.o = o;
+    p.q_sb = q_sb; p.q_sh = q_sh; p.q_sl = q_sl;
+    p.k_sb = k_sb; p.k_sh = k_sh; p.k_sl = k_sl;
+    p.v_sb = v_sb; p.v_sh = v_sh; p.v_sl = v_sl;
+    p.o_sb = o_sb; p.o_sl = o_sl; p.o_sh = o_sh;
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.L = L;
+    p.G = Hq / Hkv;
+    p.HG = (p.G + 3) / 4;
+    p.n_units = desc_host[H_NUNITS];
+    p.out_f32 = out_dtype == SDAG_OUT_F32;
+    p.c = scale * 1.4426950408889634f;
+    p.desc = desc_dev;
+    const int64_t n_slots = desc_host[H_NSLOTS];
+    float* ws = (float*)workspace;
+    p.part_o = ws;
+    p.part_ml = ws + n_slots * B * Hq * RB * D;
+    p.vsum = p.part_ml + n_slots * B * Hq * RB * 2;
+    const int n_uni = desc_host[H_NUNIFORM];
+    const int64_t main_blocks = (int64_t)p.n_units * Hkv * p.HG * B;
+    const int64_t vsum_blocks = n_uni > 0 ? (int64_t)B * Hkv * VSUM_CHUNKS : 0;
+    if (main_blocks + vsum_blocks > 0x7fffffff) return fail(SDAG_ERR_ARG, "grid too large");
+    p.n_main_blocks = (int)main_blocks;
+    hipStream_t st = (hipStream_t)stream;
+    if (main_blocks + vsum_blocks > 0) {
+        hipLaunchKernelGGL(sdag_attn_main, dim3((unsigned)(main_blocks + vsum_blocks)), dim3(256), 0, st, p);
+        SDAG_HIP_CHECK(hipGetLastError());
+    }
+    const int n_merge = desc_host[H_NSPLIT] * B * Hq;
+    const int64_t n_pairs = (int64_t)n_uni * B * Hq;
+    const int64_t cblocks = n_merge + (n_pairs + 7) / 8;
+    if (cblocks > 0) {
+        hipLaunchKernelGGL(sdag_attn_combine, dim3((unsigned)cblocks), dim3(256), 0, st, p, n_merge);
+        SDAG_HIP_CHECK(hipGetLastError());
+    }
+    return SDAG_OK;
+}
+
+extern "C" int sdag_mask_materialize(const int32_t* desc_host, const int32_t* desc_dev, uint8_t* out_dev, void* stream) {
+    if (!desc_ok(desc_host)) return fail(SDAG_ERR_DESC, "desc_host is not a descriptor");
+    if (!desc_dev || !out_dev) return fail(SDAG_ERR_ARG, "NULL pointer");
+    const int nrb = desc_host[H_NRB];
+    if (nrb == 0) return SDAG_OK;
+    hipLaunchKernelGGL(sdag_mask_expand, dim3(nrb), dim3(256), 0, (hipStream_t)stream, desc_dev, out_dev);
+    SDAG_HIP_CHECK(hipGetLastError());
+    return SDAG_OK;
+}

@@ -1,0 +1,243 @@
+// Host-side builder of the block-sparse attention descriptor (see common.h for the word layout).
+//
+// The reference fills an L x L boolean tensor row by row (src/pipeline/sparse_attention_RAG/SDAG.py:104-127).
+// Here the same relation is produced 32 rows at a time as one 64-bit word per (row, key tile) and immediately
+// reduced to: skipped tiles, fully allowed tiles, and partially allowed tiles that keep their 32 x 64 bit mask.
+#include <algorithm>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#include "common.h"
+
+namespace sdag {
+
+static thread_local char g_err[512] = "";
+char* err_buf() { return g_err; }
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+namespace {
+
+constexpr int RB = SDAG_ROW_BLOCK;
+constexpr int KT = SDAG_KV_TILE;
+static_assert(RB == 32 && KT == 64, "descriptor masks are 32 rows of one 64-bit word");
+
+inline void set_range(uint64_t* row_bits, int a, int b) {  // columns [a, b), b > a
+    const int t0 = a >> 6, t1 = (b - 1) >> 6;
+    for (int t = t0; t <= t1; ++t) {
+        const int lo = t == t0 ? (a & 63) : 0;
+        const int hi = t == t1 ? ((b - 1) & 63) : 63;  // inclusive
+        const uint64_t m = (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1)) & ~((1ull << lo) - 1);
+        row_bits[t] |= m;
+    }
+}
+
+// fill(rb, bits): bits is RB * nkt words, zeroed by the caller; bits[r * nkt + t].
+using FillFn = std::function<void(int, uint64_t*)>;
+
+int emit(int L, const FillFn& fill, int max_items_per_unit, int32_t* out, int64_t cap_words, int64_t* n_words) {
+    const int nrb = (L + RB - 1) / RB;
+    const int nkt = (L + KT - 1) / KT;
+    std::vector<uint64_t> bits((size_t)RB * std::max(nkt, 1));
+    std::vector<int32_t> items;            // {kt, mask}
+    std::vector<int32_t> rb_item_begin(nrb + 1, 0);
+    std::vector<uint64_t> masks;           // 32 words per mask
+    std::vector<int32_t> rbinfo((size_t)nrb * 2, 0);
+    std::vector<int32_t> uniform;
+    int64_t pairs = 0;
+
+    for (int rb = 0; rb < nrb; ++rb) {
+        std::fill(bits.begin(), bits.end(), 0ull);
+        fill(rb, bits.data());
+        uint32_t uni = 0;
+        const int rows = std::min(RB, L - rb * RB);
+        for (int r = 0; r < rows; ++r) {
+            uint64_t any = 0;
+            for (int t = 0; t < nkt; ++t) any |= bits[(size_t)r * nkt + t];
+            if (!any) {
+                uni |= 1u << r;
+                uniform.push_back(rb * RB + r);
+            }
+        }
+        rbinfo[(size_t)rb * 2] = (int32_t)uni;
+        for (int t = 0; t < nkt; ++t) {
+            uint64_t any = 0, all = ~0ull;
+            for (int r = 0; r < RB; ++r) {
+                const uint64_t w = bits[(size_t)r * nkt + t];
+                any |= w;
+                all &= w;
+                pairs += __builtin_popcountll(w);
+            }
+            if (!any) continue;
+            items.push_back(t);
+            if (all == ~0ull) {
+                items.push_back(-1);
+            } else {
+                items.push_back((int32_t)(masks.size() / RB));
+                for (int r = 0; r < RB; ++r) masks.push_back(bits[(size_t)r * nkt + t]);
+            }
+        }
+        rb_item_begin[rb + 1] = (int32_t)(items.size() / 2);
+    }
+
+    const int n_items = (int)(items.size() / 2);
+    int T = max_items_per_unit;
+    if (T <= 0) {
+        // Default: keep enough units in flight to cover the chip for one KV head group, but never make a
+        // unit so short that the merge of its partial result costs more than walking the tiles.
+        T = (n_items + 47) / 48;
+        T = std::max(8, std::min(64, T));
+    }
+
+    struct Unit { int32_t rb, b, e, slot; };
+    std::vector<Unit> units;
+    std::vector<int32_t> split;
+    int n_slots = 0;
+    for (int rb = 0; rb < nrb; ++rb) {
+        const int b = rb_item_begin[rb], e = rb_item_begin[rb + 1], n = e - b;
+        if (n == 0) continue;
+        if (n <= T) {
+            units.push_back({rb, b, e, -1});
+            continue;
+        }
+        const int nch = (n + T - 1) / T;
+        const int per = (n + nch - 1) / nch;
+        split.push_back(rb);
+        split.push_back(n_slots);
+        int made = 0;
+        for (int s = b; s < e; s += per, ++made) units.push_back({rb, s, std::min(e, s + per), n_slots + made});
+        split.push_back(made);
+        split.push_back(0);
+        n_slots += made;
+    }
+    std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& c) { return (a.e - a.b) > (c.e - c.b); });
+
+    int64_t off = H_WORDS;
+    const int64_t off_units = off;  off += (int64_t)units.size() * 4;
+    const int64_t off_items = off;  off += (int64_t)n_items * 2;
+    if (off & 1) ++off;
+    const int64_t off_masks = off;  off += (int64_t)masks.size() * 2;
+    const int64_t off_rbinfo = off; off += (int64_t)nrb * 2;
+    const int64_t off_split = off;  off += (int64_t)split.size();
+    const int64_t off_uniform = off; off += (int64_t)uniform.size();
+    const int64_t total = off;
+    if (n_words) *n_words = total;
+    if (total > 0x7fffffff) return fail(SDAG_ERR_ARG, "descriptor too large (%lld words)", (long long)total);
+    if (!out || cap_words < total) return fail(SDAG_ERR_CAPACITY, "descriptor needs %lld words, buffer has %lld", (long long)total, (long long)cap_words);
+
+    std::memset(out, 0, sizeof(int32_t) * H_WORDS);
+    out[H_MAGIC] = DESC_MAGIC;
+    out[H_VERSION] = DESC_VERSION;
+    out[H_L] = L;
+    out[H_NRB] = nrb;
+    out[H_NKT] = nkt;
+    out[H_NUNITS] = (int32_t)units.size();
+    out[H_NITEMS] = n_items;
+    out[H_NMASKS] = (int32_t)(masks.size() / RB);
+    out[H_NSPLIT] = (int32_t)(split.size() / 4);
+    out[H_NUNIFORM] = (int32_t)uniform.size();
+    out[H_OFF_UNITS] = (int32_t)off_units;
+    out[H_OFF_ITEMS] = (int32_t)off_items;
+    out[H_OFF_MASKS] = (int32_t)off_masks;
+    out[H_OFF_RBINFO] = (int32_t)off_rbinfo;
+    out[H_OFF_SPLIT] = (int32_t)off_split;
+    out[H_OFF_UNIFORM] = (int32_t)off_uniform;
+    out[H_TOTAL_WORDS] = (int32_t)total;
+    out[H_NSLOTS] = n_slots;
+    out[H_PAIRS_LO] = (int32_t)(uint32_t)(pairs & 0xffffffffll);
+    out[H_PAIRS_HI] = (int32_t)(uint32_t)((uint64_t)pairs >> 32);
+    for (size_t u = 0; u < units.size(); ++u) {
+        int32_t* p = out + off_units + u * 4;
+        p[0] = units[u].rb; p[1] = units[u].b; p[2] = units[u].e; p[3] = units[u].slot;
+    }
+    if (n_items) std::memcpy(out + off_items, items.data(), sizeof(int32_t) * items.size());
+    if (off_masks > off_items + (int64_t)n_items * 2) out[off_masks - 1] = 0;
+    if (!masks.empty()) std::memcpy(out + off_masks, masks.data(), sizeof(uint64_t) * masks.size());
+    if (nrb) std::memcpy(out + off_rbinfo, rbinfo.data(), sizeof(int32_t) * rbinfo.size());
+    if (!split.empty()) std::memcpy(out + off_split, split.data(), sizeof(int32_t) * split.size());
+    if (!uniform.empty()) std::memcpy(out + off_uniform, uniform.data(), sizeof(int32_t) * uniform.size());
+    return SDAG_OK;
+}
+
+}  // namespace
+}  // namespace sdag
+
+using namespace sdag;
+
+extern "C" int sdag_version(void) { return 1; }
+extern "C" const char* sdag_last_error(void) { return err_buf(); }
+
+extern "C" int sdag_desc_build(int L, int sys_user_len, int n_docs, const int32_t* spans, int qa_start,
+                               const int32_t* nbr_off, const int32_t* nbr_idx, int max_items_per_unit,
+                               int32_t* out, int64_t cap_words, int64_t* n_words) {
+    if (L < 0 || n_docs < 0) return fail(SDAG_ERR_ARG, "negative L or n_docs");
+    if (sys_user_len < 0 || sys_user_len > L) return fail(SDAG_ERR_ARG, "sys_user_len %d outside [0, %d]", sys_user_len, L);
+    if (qa_start < 0) return fail(SDAG_ERR_ARG, "qa_start negative");
+    if (n_docs > 0 && !spans) return fail(SDAG_ERR_ARG, "spans is NULL");
+    for (int d = 0; d < n_docs; ++d) {
+        const int s = spans[2 * d], e = spans[2 * d + 1];
+        if (s < 0 || e < 0 || s > L || e > L) return fail(SDAG_ERR_ARG, "document %d span (%d, %d) outside [0, %d]", d, s, e, L);
+    }
+    if (nbr_off) {
+        if (nbr_off[0] != 0) return fail(SDAG_ERR_ARG, "nbr_off[0] must be 0");
+        for (int d = 0; d < n_docs; ++d)
+            if (nbr_off[d + 1] < nbr_off[d]) return fail(SDAG_ERR_ARG, "nbr_off not monotone");
+        if (n_docs > 0 && nbr_off[n_docs] > 0 && !nbr_idx) return fail(SDAG_ERR_ARG, "nbr_idx is NULL");
+    }
+    const int nkt = (L + SDAG_KV_TILE - 1) / SDAG_KV_TILE;
+    auto fill = [&](int rb, uint64_t* bits) {
+        const int r0 = rb * SDAG_ROW_BLOCK, r1 = std::min(L, r0 + SDAG_ROW_BLOCK);
+        for (int i = r0; i < r1; ++i) {
+            uint64_t* row = bits + (size_t)(i - r0) * nkt;
+            if (i < sys_user_len || i >= qa_start) set_range(row, 0, i + 1);  // SDAG.py:107-108, 124-125
+            for (int d = 0; d < n_docs; ++d) {
+                const int s = spans[2 * d], e = spans[2 * d + 1];
+                if (i < s || i >= e) continue;
+                if (sys_user_len > 0) set_range(row, 0, sys_user_len);  // SDAG.py:115
+                set_range(row, s, i + 1);                               // SDAG.py:116
+                if (nbr_off) {
+                    for (int t = nbr_off[d]; t < nbr_off[d + 1]; ++t) {  // SDAG.py:118-122
+                        const int nb = nbr_idx[t];
+                        if (nb < 0 || nb >= n_docs) continue;
+                        const int ns = spans[2 * nb], ne = spans[2 * nb + 1];
+                        if (ne > ns) set_range(row, ns, ne);
+                    }
+                }
+            }
+        }
+    };
+    return emit(L, fill, max_items_per_unit, out, cap_words, n_words);
+}
+
+extern "C" int sdag_desc_from_dense(const uint8_t* mask, int L, int max_items_per_unit, int32_t* out,
+                                    int64_t cap_words, int64_t* n_words) {
+    if (L < 0 || (L > 0 && !mask)) return fail(SDAG_ERR_ARG, "bad dense mask");
+    const int nkt = (L + SDAG_KV_TILE - 1) / SDAG_KV_TILE;
+    auto fill = [&](int rb, uint64_t* bits) {
+        const int r0 = rb * SDAG_ROW_BLOCK, r1 = std::min(L, r0 + SDAG_ROW_BLOCK);
+        for (int i = r0; i < r1; ++i) {
+            const uint8_t* src = mask + (size_t)i * L;
+            uint64_t* row = bits + (size_t)(i - r0) * nkt;
+            for (int j = 0; j < L; ++j)
+                if (src[j]) row[j >> 6] |= 1ull << (j & 63);
+        }
+    };
+    return emit(L, fill, max_items_per_unit, out, cap_words, n_words);
+}
+
+extern "C" int sdag_desc_stats(const int32_t* d, int64_t* allowed_pairs, int32_t* n_uniform_rows,
+                               int32_t* n_units, int32_t* n_items, int32_t* n_partial_tiles) {
+    if (!desc_ok(d)) return fail(SDAG_ERR_DESC, "not a descriptor");
+    if (allowed_pairs) *allowed_pairs = (int64_t)(((uint64_t)(uint32_t)d[H_PAIRS_HI] << 32) | (uint32_t)d[H_PAIRS_LO]);
+    if (n_uniform_rows) *n_uniform_rows = d[H_NUNIFORM];
+    if (n_units) *n_units = d[H_NUNITS];
+    if (n_items) *n_items = d[H_NITEMS];
+    if (n_partial_tiles) *n_partial_tiles = d[H_NMASKS];
+    return SDAG_OK;
+}

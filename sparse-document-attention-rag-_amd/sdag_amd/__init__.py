@@ -1,0 +1,16 @@
+"""MI355X-native SDAG attention prefill and dense-retrieval search (host side).
+
+Python stays thin: device memory, streams and process groups come from PyTorch-ROCm, the arithmetic runs in
+the HIP kernels of libsdag_hip.so (``csrc/``), reached through the C ABI declared in ``include/sdag_hip.h``.
+"""
+from . import _lib
+from ._lib import SdagError, build
+from .attention import sdag_attention
+from .descriptor import Descriptor, from_dense, from_spans
+from .index import FlatIPIndex, ShardedFlatIPIndex, merge_partial_topk, shard_bounds
+from .ops import centroid_sims, doc_knn, gram
+
+__all__ = [
+    "SdagError", "build", "sdag_attention", "Descriptor", "from_dense", "from_spans", "FlatIPIndex",
+    "ShardedFlatIPIndex", "merge_partial_topk", "shard_bounds", "centroid_sims", "doc_knn", "gram",
+]

@@ -1,0 +1,81 @@
+"""SDAG masked attention prefill on the HIP kernel (``sdag_attn_fwd``).
+
+Replaces the attention call the reference reaches through ``model(input_ids, attention_mask=[1,1,L,L])``
+(src/pipeline/sparse_attention_RAG/SDAG.py:176): same inputs and output layout as a transformers attention
+function -- query [B, Hq, L, D], key / value [B, Hkv, L, D] (any batch / head / row strides, D contiguous),
+output [B, L, Hq, D].
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from .descriptor import Descriptor
+
+_workspaces: Dict[torch.device, torch.Tensor] = {}
+
+
+def _workspace(device: torch.device, nbytes: int) -> Optional[torch.Tensor]:
+    if nbytes == 0:
+        return None
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
+def sdag_attention(
+    query: torch.Tensor,
+    key: torch.Tensor,
+    value: torch.Tensor,
+    desc: Descriptor,
+    scaling: Optional[float] = None,
+    out_dtype: torch.dtype = torch.bfloat16,
+    out: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """softmax(Q K^T * scaling + M) V with M described by ``desc``; returns [B, L, Hq, D]."""
+    if not (query.is_cuda and key.is_cuda and value.is_cuda):
+        raise RuntimeError("sdag_attention runs on the GPU only (no CPU fallback)")
+    if query.dtype != torch.bfloat16 or key.dtype != torch.bfloat16 or value.dtype != torch.bfloat16:
+        raise TypeError("sdag_attention takes bf16 query/key/value")
+    B, Hq, L, D = query.shape
+    Bk, Hkv, S, Dk = key.shape
+    if value.shape != key.shape or Bk != B or Dk != D or S != L:
+        raise ValueError(f"shape mismatch: q {tuple(query.shape)} k {tuple(key.shape)} v {tuple(value.shape)}")
+    if desc.L != L:
+        raise ValueError(f"descriptor is for L={desc.L}, tensors have L={L}")
+    if query.stride(3) != 1:
+        query = query.contiguous()
+    if key.stride(3) != 1:
+        key = key.contiguous()
+    if value.stride(3) != 1:
+        value = value.contiguous()
+    if scaling is None:
+        scaling = D ** -0.5
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError("out_dtype must be bfloat16 or float32")
+    dev = query.device
+    if out is None:
+        out = torch.empty((B, L, Hq, D), dtype=out_dtype, device=dev)
+    elif out.shape != (B, L, Hq, D) or out.dtype != out_dtype or out.stride(3) != 1 or out.device != dev:
+        raise ValueError("bad out tensor")
+    ws_bytes = desc.workspace_bytes(B, Hq, Hkv)
+    ws = _workspace(dev, ws_bytes)
+    ddev = desc.device(dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().sdag_attn_fwd(
+            query.data_ptr(), key.data_ptr(), value.data_ptr(), out.data_ptr(),
+            query.stride(0), query.stride(1), query.stride(2),
+            key.stride(0), key.stride(1), key.stride(2),
+            value.stride(0), value.stride(1), value.stride(2),
+            out.stride(0), out.stride(1), out.stride(2),
+            B, Hq, Hkv, L, D, float(scaling),
+            desc.host_ptr, ddev.data_ptr(),
+            ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+            _lib.OUT_F32 if out_dtype == torch.float32 else _lib.OUT_BF16,
+            _lib.stream_ptr(dev))
+    _lib.check(rc)
+    return out

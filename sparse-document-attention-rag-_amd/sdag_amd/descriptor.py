@@ -1,0 +1,158 @@
+"""Block-sparse attention descriptors: the replacement for the reference's dense L x L mask.
+
+The reference builds ``torch.bool [L, L]`` with Python row loops
+(src/pipeline/sparse_attention_RAG/SDAG.py:104-127).  A descriptor holds the same relation as work items
+over 32-row x 64-key tiles plus bit masks for partially allowed tiles; it is built on the host by
+``sdag_desc_build`` (C++) in time proportional to L x (documents + tiles), uploaded once per prompt and
+shared by every layer and head.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+H_L, H_NRB, H_NKT, H_NUNITS, H_NITEMS, H_NMASKS, H_NSPLIT, H_NUNIFORM = 2, 3, 4, 5, 6, 7, 8, 9
+H_NSLOTS = 17
+
+_scratch = np.empty(1 << 16, dtype=np.int32)
+
+
+class Descriptor:
+    """Host copy (numpy int32) + lazily created device copies of one descriptor."""
+
+    def __init__(self, words: np.ndarray):
+        self.host = np.ascontiguousarray(words, dtype=np.int32)
+        self._dev: Dict[torch.device, torch.Tensor] = {}
+
+    # ---- header fields
+    @property
+    def L(self) -> int:
+        return int(self.host[H_L])
+
+    @property
+    def n_units(self) -> int:
+        return int(self.host[H_NUNITS])
+
+    @property
+    def n_items(self) -> int:
+        return int(self.host[H_NITEMS])
+
+    @property
+    def n_partial_tiles(self) -> int:
+        return int(self.host[H_NMASKS])
+
+    @property
+    def n_uniform_rows(self) -> int:
+        return int(self.host[H_NUNIFORM])
+
+    @property
+    def n_slots(self) -> int:
+        return int(self.host[H_NSLOTS])
+
+    @property
+    def allowed_pairs(self) -> int:
+        pairs = ctypes.c_int64(0)
+        _lib.check(_lib.lib().sdag_desc_stats(self.host.ctypes.data, ctypes.byref(pairs), None, None, None, None))
+        return int(pairs.value)
+
+    @property
+    def host_ptr(self) -> int:
+        return self.host.ctypes.data
+
+    def device(self, device) -> torch.Tensor:
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        t = self._dev.get(device)
+        if t is None:
+            t = torch.from_numpy(self.host).to(device)
+            self._dev[device] = t
+        return t
+
+    def workspace_bytes(self, B: int, Hq: int, Hkv: int) -> int:
+        n = _lib.lib().sdag_attn_workspace_bytes(self.host_ptr, B, Hq, Hkv)
+        if n < 0:
+            raise _lib.SdagError(-1, "bad workspace query")
+        return int(n)
+
+    def materialize(self, device) -> torch.Tensor:
+        """Dense ``torch.bool [L, L]`` on ``device`` (what build_blocked_causal_mask_full returns)."""
+        dev = self.device(device)
+        out = torch.empty((self.L, self.L), dtype=torch.uint8, device=dev.device)
+        if self.L:
+            with torch.cuda.device(dev.device):
+                _lib.check(_lib.lib().sdag_mask_materialize(self.host_ptr, dev.data_ptr(), out.data_ptr(),
+                                                            _lib.stream_ptr(dev.device)))
+        return out.view(torch.bool)
+
+
+def _run_builder(call) -> np.ndarray:
+    global _scratch
+    need = ctypes.c_int64(0)
+    rc = call(_scratch.ctypes.data, _scratch.size, ctypes.byref(need))
+    if rc == _lib.SDAG_ERR_CAPACITY:
+        _scratch = np.empty(int(need.value) * 2, dtype=np.int32)
+        rc = call(_scratch.ctypes.data, _scratch.size, ctypes.byref(need))
+    _lib.check(rc)
+    return _scratch[: int(need.value)].copy()
+
+
+def from_spans(
+    base_seq_len: int,
+    sys_user_len: int,
+    doc_token_spans: Sequence[Tuple[int, int]],
+    qa_start: int,
+    doc_neighbors: Optional[Sequence[Sequence[int]]] = None,
+    max_items_per_unit: int = 0,
+) -> Descriptor:
+    """Descriptor of the SDAG mask; argument meaning as in build_blocked_causal_mask_full (SDAG.py:68-76).
+
+    ``doc_neighbors`` is ignored unless it has one entry per document (SDAG.py:111).  Values the reference
+    would index out of range with (negative positions, spans past L) raise ``ValueError``.
+    """
+    n_docs = len(doc_token_spans)
+    spans = np.asarray([int(x) for se in doc_token_spans for x in se], dtype=np.int32).reshape(-1)
+    use_nbr = doc_neighbors is not None and len(doc_neighbors) == n_docs
+    nbr_off = nbr_idx = None
+    if use_nbr:
+        lens = [len(n) for n in doc_neighbors]
+        nbr_off = np.zeros(n_docs + 1, dtype=np.int32)
+        nbr_off[1:] = np.cumsum(lens)
+        flat = [int(x) for n in doc_neighbors for x in n]
+        # ids that do not fit int32 are out of range by definition; keep them out of range
+        flat = [x if -(2 ** 31) <= x < 2 ** 31 else -1 for x in flat]
+        nbr_idx = np.asarray(flat, dtype=np.int32)
+    lib = _lib.lib()
+
+    def call(out_ptr, cap, need):
+        return lib.sdag_desc_build(int(base_seq_len), int(sys_user_len), n_docs, spans.ctypes.data if n_docs else None,
+                                   int(qa_start), nbr_off.ctypes.data if use_nbr else None,
+                                   nbr_idx.ctypes.data if use_nbr and nbr_idx.size else None,
+                                   int(max_items_per_unit), out_ptr, cap, need)
+
+    try:
+        return Descriptor(_run_builder(call))
+    except _lib.SdagError as e:
+        if e.code == _lib.SDAG_ERR_ARG:
+            raise ValueError(str(e)) from None
+        raise
+
+
+def from_dense(mask, max_items_per_unit: int = 0) -> Descriptor:
+    """Descriptor of an arbitrary boolean [L, L] mask (numpy or torch, any device)."""
+    if isinstance(mask, torch.Tensor):
+        mask = mask.detach().to("cpu").numpy()
+    m = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+    if m.ndim != 2 or m.shape[0] != m.shape[1]:
+        raise ValueError("mask must be square [L, L]")
+    lib = _lib.lib()
+
+    def call(out_ptr, cap, need):
+        return lib.sdag_desc_from_dense(m.ctypes.data, m.shape[0], int(max_items_per_unit), out_ptr, cap, need)
+
+    return Descriptor(_run_builder(call))

@@ -1,0 +1,167 @@
+"""Exact inner-product index resident in HBM: the object the reference calls ``index``.
+
+The reference does ``scores, indices = index.search(q.astype(np.float32), top_k)`` on whatever
+``faiss.read_index`` returned (src/pipeline/retrieval/dense.py:36,82-84).  ``FlatIPIndex`` offers that duck
+type (``search``, ``ntotal``, ``d``, ``add``) with the corpus kept as one fp32 [N, d] array on the GPU and the
+search done by ``sdag_dense_topk``.  ``ShardedFlatIPIndex`` row-shards the corpus over the ranks of a
+``torch.distributed`` process group: every rank searches its shard with global ids, one all-gather moves the
+packed partial lists, and every rank merges them with the same (score desc, id asc) rule.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+MAX_K = 32
+
+
+def _as_f32_2d(x, name: str) -> np.ndarray:
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    if a.ndim != 2:
+        raise ValueError(f"{name} must be 2-D")
+    return a
+
+
+class FlatIPIndex:
+    """faiss.IndexFlatIP-shaped exact search on one GPU."""
+
+    def __init__(self, d: int, device="cuda:0", id_base: int = 0):
+        if d <= 0 or d % 32:
+            raise ValueError("d must be a positive multiple of 32")
+        self.d = int(d)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("FlatIPIndex lives on the GPU (no CPU fallback)")
+        self.id_base = int(id_base)
+        self._corpus: Optional[torch.Tensor] = None  # [N, d] fp32
+        self._ws: Optional[torch.Tensor] = None
+
+    # ---- faiss-like surface
+    @property
+    def ntotal(self) -> int:
+        return 0 if self._corpus is None else int(self._corpus.shape[0])
+
+    def add(self, x) -> None:
+        """Append rows (numpy on the host or a torch tensor on any device)."""
+        if isinstance(x, torch.Tensor):
+            t = x.detach().to(self.device, dtype=torch.float32)
+            if t.dim() != 2:
+                raise ValueError("x must be 2-D")
+        else:
+            t = torch.from_numpy(_as_f32_2d(x, "x")).to(self.device)
+        if t.shape[1] != self.d:
+            raise ValueError(f"x has dimension {t.shape[1]}, index has {self.d}")
+        t = t.contiguous()
+        self._corpus = t if self._corpus is None else torch.cat([self._corpus, t], dim=0)
+
+    def reset(self) -> None:
+        self._corpus = None
+
+    def search(self, q, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        """(scores f32 [nq, k], ids i64 [nq, k]) as numpy, best first -- the faiss return order."""
+        qa = _as_f32_2d(q, "q")
+        s, i = self.search_device(torch.from_numpy(qa).to(self.device), k)
+        return s.cpu().numpy(), i.cpu().numpy()
+
+    # ---- device-resident variant (no host round trip)
+    def search_device(self, q: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        if q.dim() != 2 or q.shape[1] != self.d:
+            raise ValueError(f"q must be [nq, {self.d}]")
+        k = int(k)
+        if k <= 0:
+            raise ValueError("k must be positive")
+        q = q.to(self.device, dtype=torch.float32).contiguous()
+        nq = q.shape[0]
+        kk = min(k, MAX_K)
+        if k > MAX_K:
+            raise ValueError(f"k={k} above the supported maximum {MAX_K}")
+        out_s = torch.empty((nq, kk), dtype=torch.float32, device=self.device)
+        out_i = torch.empty((nq, kk), dtype=torch.int64, device=self.device)
+        N = self.ntotal
+        lib = _lib.lib()
+        need = lib.sdag_dense_workspace_bytes(nq, N, self.d, kk)
+        if need < 0:
+            raise _lib.SdagError(-1, "bad workspace query")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(int(need), 256), dtype=torch.uint8, device=self.device)
+        cptr = self._corpus.data_ptr() if N else None
+        with torch.cuda.device(self.device):
+            rc = lib.sdag_dense_topk(q.data_ptr(), nq, cptr, N, self.d, kk, out_s.data_ptr(), out_i.data_ptr(),
+                                     self.id_base, self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr(self.device))
+        _lib.check(rc)
+        return out_s, out_i
+
+
+def merge_partial_topk(parts_s: torch.Tensor, parts_i: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[n_parts, nq, k] partial lists (device) -> best k per query by (score desc, id asc)."""
+    n_parts, nq, kk = parts_s.shape
+    if kk != k or parts_i.shape != parts_s.shape:
+        raise ValueError("partial lists must be [n_parts, nq, k]")
+    parts_s = parts_s.contiguous().float()
+    parts_i = parts_i.contiguous().to(torch.int64)
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=parts_s.device)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=parts_s.device)
+    with torch.cuda.device(parts_s.device):
+        rc = _lib.lib().sdag_topk_merge(parts_s.data_ptr(), parts_i.data_ptr(), n_parts, nq, k, out_s.data_ptr(),
+                                        out_i.data_ptr(), _lib.stream_ptr(parts_s.device))
+    _lib.check(rc)
+    return out_s, out_i
+
+
+def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous row range of ``rank``: shards of ceil(N / world) rows, the last ones possibly short or empty."""
+    per = (n_total + world - 1) // world
+    lo = min(n_total, rank * per)
+    return lo, min(n_total, lo + per)
+
+
+def pack_partial(scores: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    """One int64 buffer [nq, k, 2] per rank (score bits, id) so a single all-gather moves both."""
+    return torch.stack([scores.contiguous().view(torch.int32).to(torch.int64), ids], dim=-1).contiguous()
+
+
+def unpack_partial(buf: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    return buf[..., 0].to(torch.int32).view(torch.float32), buf[..., 1].contiguous()
+
+
+class ShardedFlatIPIndex:
+    """Row-sharded exact search: local top-k with global ids -> one all-gather -> identical merge on every rank."""
+
+    def __init__(self, d: int, n_total: int, device, group=None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n_total = int(n_total)
+        self.lo, self.hi = shard_bounds(self.n_total, self.world, self.rank)
+        self.local = FlatIPIndex(d, device=device, id_base=self.lo)
+        self.d = d
+
+    @property
+    def ntotal(self) -> int:
+        return self.n_total
+
+    def add_local(self, x) -> None:
+        """Rows [lo, hi) of the global corpus, in order."""
+        self.local.add(x)
+        if self.local.ntotal > self.hi - self.lo:
+            raise ValueError("more rows than this rank's shard holds")
+
+    def search_device(self, q: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        s, i = self.local.search_device(q, k)
+        mine = pack_partial(s, i)
+        gathered = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+        self.dist.all_gather_into_tensor(gathered, mine, group=self.group)
+        ps, pi = unpack_partial(gathered)
+        return merge_partial_topk(ps, pi, k)
+
+    def search(self, q, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        qa = _as_f32_2d(q, "q")
+        s, i = self.search_device(torch.from_numpy(qa).to(self.local.device), k)
+        return s.cpu().numpy(), i.cpu().numpy()

@@ -1,0 +1,96 @@
+"""First GPU parity checks: descriptor expansion, attention vs the fp32 oracle, exact search vs the C oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, golden_bits, load_masks, mask_sha, synthetic_layout
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def test_mask_materialize_matches_golden():
+    import sdag_amd
+
+    g = load_masks()
+    for c in g["small"]:
+        d = sdag_amd.from_spans(c["L"], c["sys"], c["spans"], c["qa"], c["nbr"])
+        m = d.materialize(_dev()).cpu().numpy()
+        assert np.array_equal(m, golden_bits(c)), c
+    for c in g["big"]:
+        d = sdag_amd.from_spans(c["L"], c["sys"], c["spans"], c["qa"], c["nbr"])
+        m = d.materialize(_dev()).cpu().numpy()
+        assert mask_sha(m) == c["sha256"], c["name"]
+
+
+def _rel_err(o, ref):
+    # per head: max |o - ref| / max |ref|
+    num = (o - ref).abs().amax(dim=(0, 1, 3))
+    den = ref.abs().amax(dim=(0, 1, 3))
+    return float((num / den).max())
+
+
+@pytest.mark.parametrize("name", ["toy", "mid", "nbr"])
+def test_attention_golden(name):
+    import json
+
+    import sdag_amd
+    from oracle import sdag_ref
+
+    z = np.load(f"{GOLDEN}/attention.npz")
+    meta = json.loads(bytes(z[f"{name}_meta"]).decode())
+    q = torch.from_numpy(z[f"{name}_q"]).view(torch.bfloat16)
+    k = torch.from_numpy(z[f"{name}_k"]).view(torch.bfloat16)
+    v = torch.from_numpy(z[f"{name}_v"]).view(torch.bfloat16)
+    ref = torch.from_numpy(z[f"{name}_o_f32"])
+    d = sdag_amd.from_spans(meta["L"], meta["sys"], meta["spans"], meta["qa"], meta["nbr"])
+    o = sdag_amd.sdag_attention(q.to(_dev()), k.to(_dev()), v.to(_dev()), d, out_dtype=torch.float32).cpu()
+    assert torch.isfinite(o).all()
+    err = _rel_err(o, ref)
+    print(name, "rel err fp32-out", err)
+    assert err <= 1e-3
+    ob = sdag_amd.sdag_attention(q.to(_dev()), k.to(_dev()), v.to(_dev()), d, out_dtype=torch.bfloat16).cpu()
+    assert torch.equal(ob, o.to(torch.bfloat16))
+
+
+def test_attention_cfg3_full_size_two_kv_heads():
+    import sdag_amd
+    from oracle import sdag_ref
+
+    spans, qa, L = synthetic_layout(60, [300] * 10, 1, 30)
+    Hq, Hkv, D = 8, 2, 128
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn(1, Hq, L, D, generator=g).to(torch.bfloat16)
+    k = torch.randn(1, Hkv, L, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(1, Hkv, L, D, generator=g).to(torch.bfloat16)
+    mask = torch.from_numpy(sdag_ref.mask_from_spans(L, 60, spans, qa, None))
+    ref = sdag_ref.masked_attention(q, k, v, mask, D ** -0.5)
+    d = sdag_amd.from_spans(L, 60, spans, qa, None)
+    o = sdag_amd.sdag_attention(q.to(_dev()), k.to(_dev()), v.to(_dev()), d, out_dtype=torch.float32).cpu()
+    err = _rel_err(o, ref)
+    print("cfg3 rel err", err)
+    assert err <= 1e-3
+
+
+@pytest.mark.parametrize("N,d,nq,k", [(1000, 64, 7, 5), (4096, 768, 32, 5), (20000, 1024, 32, 10), (333, 128, 40, 21),
+                                      (7, 32, 3, 10)])
+def test_dense_topk_bit_exact(N, d, nq, k):
+    import sdag_amd
+    from oracle import dense_ref
+
+    rng = np.random.default_rng(N + d)
+    C = rng.standard_normal((N, d), dtype=np.float32)
+    C /= np.linalg.norm(C, axis=1, keepdims=True)
+    Q = rng.standard_normal((nq, d), dtype=np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    if N >= 1000:
+        C[N // 2] = C[N // 3]  # an exact tie: the lower id must come first
+    rs, ri = dense_ref.dense_topk(Q, C, k, id_base=5)
+    idx = sdag_amd.FlatIPIndex(d, device=_dev(), id_base=5)
+    idx.add(C)
+    s, i = idx.search(Q, k)
+    assert np.array_equal(i, ri)
+    assert np.array_equal(s.view(np.uint32), rs.view(np.uint32))
