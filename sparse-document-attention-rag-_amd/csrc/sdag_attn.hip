@@ -242,12 +242,25 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = fast_exp2((m_run - m_safe) * c);
         const float msc = m_safe * c;
-        float rs = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             s0[i] = fast_exp2(__builtin_fmaf(s0[i], c, -msc));
             s1[i] = fast_exp2(__builtin_fmaf(s1[i], c, -msc));
-            rs += s0[i] + s1[i];
+        }
+
+        // ---- P^T fragments: registers 8 s .. 8 s + 7 of block kb are k-step (kb, s) of the B operand.
+        // The row sum is taken over the bf16-rounded probabilities, the values the MFMA multiplies with, so
+        // that the output stays an exact convex combination of V rows: the rounding error of a dominant
+        // key then cancels against the normaliser instead of scaling the whole row.
+        bf16x8 pf[2][2];
+        float rs = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            pf[0][0][j] = (__bf16)s0[j];
+            pf[0][1][j] = (__bf16)s0[8 + j];
+            pf[1][0][j] = (__bf16)s1[j];
+            pf[1][1][j] = (__bf16)s1[8 + j];
+            rs += ((float)pf[0][0][j] + (float)pf[0][1][j]) + ((float)pf[1][0][j] + (float)pf[1][1][j]);
         }
         rs += __shfl_xor(rs, 32);
         l_run = l_run * alpha + rs;
@@ -257,16 +270,6 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
             for (int db = 0; db < 4; ++db)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
-        }
-
-        // ---- P^T fragments: registers 8 s .. 8 s + 7 of block kb are k-step (kb, s) of the B operand
-        bf16x8 pf[2][2];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            pf[0][0][j] = (__bf16)s0[j];
-            pf[0][1][j] = (__bf16)s0[8 + j];
-            pf[1][0][j] = (__bf16)s1[j];
-            pf[1][1][j] = (__bf16)s1[8 + j];
         }
 
         // ---- O^T += V^T P^T

@@ -79,3 +79,38 @@ def sdag_attention(
             _lib.stream_ptr(dev))
     _lib.check(rc)
     return out
+
+
+class BoundAttention:
+    """``sdag_attention`` with every argument resolved once, for callers that reuse the same tensors
+    (static serving buffers, benchmarks): ``__call__`` is a single C call on torch's current stream."""
+
+    def __init__(self, query, key, value, desc: Descriptor, out: torch.Tensor, scaling: Optional[float] = None):
+        B, Hq, L, D = query.shape
+        Hkv = key.shape[1]
+        if query.dtype != torch.bfloat16 or key.dtype != torch.bfloat16 or value.dtype != torch.bfloat16:
+            raise TypeError("bf16 query/key/value expected")
+        if query.stride(3) != 1 or key.stride(3) != 1 or value.stride(3) != 1 or out.stride(3) != 1:
+            raise ValueError("head_dim must be contiguous")
+        if out.shape != (B, L, Hq, D) or out.dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("bad out tensor")
+        self.device = query.device
+        self._keep = (query, key, value, out, desc)
+        ws = _workspace(self.device, desc.workspace_bytes(B, Hq, Hkv))
+        self._ws = ws
+        self._fn = _lib.lib().sdag_attn_fwd
+        self._args = (
+            query.data_ptr(), key.data_ptr(), value.data_ptr(), out.data_ptr(),
+            query.stride(0), query.stride(1), query.stride(2),
+            key.stride(0), key.stride(1), key.stride(2),
+            value.stride(0), value.stride(1), value.stride(2),
+            out.stride(0), out.stride(1), out.stride(2),
+            B, Hq, Hkv, L, D, float(D ** -0.5 if scaling is None else scaling),
+            desc.host_ptr, desc.device(self.device).data_ptr(),
+            ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+            _lib.OUT_F32 if out.dtype == torch.float32 else _lib.OUT_BF16)
+
+    def __call__(self, stream: Optional[int] = None) -> None:
+        rc = self._fn(*self._args, _lib.stream_ptr(self.device) if stream is None else stream)
+        if rc:
+            _lib.check(rc)
