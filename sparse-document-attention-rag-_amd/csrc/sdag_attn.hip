@@ -31,6 +31,8 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -105,7 +107,8 @@ __device__ void vsum_block(const AttnParams& p, int vb, unsigned char* smem) {
 }
 
 __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];  // K0 K1 V0 V1
+    // K0 K1 V0 V1 tile images, then two words of V-range tags (one per V buffer)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES + 16];
 
     int bid = blockIdx.x;
     if (bid >= p.n_main_blocks) {
@@ -126,12 +129,14 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     const bool head_ok = hin < p.G;
     const int hq = kvh * p.G + (head_ok ? hin : p.G - 1);
 
-    const int32_t* desc = p.desc;
+    const int32_t* __restrict__ desc = p.desc;
     const int32_t* up = desc + desc[H_OFF_UNITS] + unit * 4;
     const int rb = up[0], it_begin = up[1], it_end = up[2], slot = up[3];
-    const int32_t* items = desc + desc[H_OFF_ITEMS];
-    const uint64_t* masks = reinterpret_cast<const uint64_t*>(desc + desc[H_OFF_MASKS]);
+    const int32_t* __restrict__ items = desc + desc[H_OFF_ITEMS];
+    const uint64_t* __restrict__ masks = reinterpret_cast<const uint64_t*>(desc + desc[H_OFF_MASKS]);
     const unsigned uniform_bits = (unsigned)desc[desc[H_OFF_RBINFO] + rb * 2];
+    unsigned* vtag = reinterpret_cast<unsigned*>(smem + 4 * TILE_BYTES);
+    if (tid < 2) vtag[tid] = 0;
 
     const int r = lane & 31;  // query row inside the block (S^T / O^T column)
     const int h = lane >> 5;
@@ -161,13 +166,46 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
             vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)kr * p.v_sl);
         }
     };
-    auto stage_store = [&](int buf) {
+    // V goes to LDS as fp16: P V then runs on the f16 MFMA with 11-bit probabilities instead of 8-bit ones.
+    // bf16 -> fp16 is exact for 2^-14 <= |v| < 2^16; round-toward-zero conversion saturates larger values
+    // instead of producing infinities, and a tag tells the consumers to redo such a tile with a scale.
+    auto stage_store = [&](int buf, unsigned seq) {
         unsigned char* kd = smem + buf * TILE_BYTES + st_off;
         unsigned char* vd = smem + (2 + buf) * TILE_BYTES + st_off;
+        float vmax = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             *reinterpret_cast<u32x4*>(kd + i * 16 * 256) = kreg[i];
-            *reinterpret_cast<u32x4*>(vd + i * 16 * 256) = vreg[i];
+            u32x4 hv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned w = vreg[i][j];
+                const float f0 = __uint_as_float(w << 16), f1 = __uint_as_float(w & 0xffff0000u);
+                vmax = fmaxf(vmax, fmaxf(fabsf(f0), fabsf(f1)));
+                hv[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(f0, f1));
+            }
+            *reinterpret_cast<u32x4*>(vd + i * 16 * 256) = hv;
+        }
+        // exponent field >= 143 means |v| >= 2^16, beyond fp16
+        const unsigned eb = (__float_as_uint(vmax) >> 23) & 0xffu;
+        if (eb >= 143u) atomicMax(&vtag[buf], (seq << 8) | eb);
+    };
+    // Slow path for a V tile with values beyond the fp16 range: every thread reloads its part of the tile and
+    // stores it scaled by 2^-e (the probabilities are scaled by 2^e to compensate).
+    auto restage_v_scaled = [&](int buf, int kt, int e) {
+        const float sc = __uint_as_float((unsigned)(127 - e) << 23);
+        unsigned char* vd = smem + (2 + buf) * TILE_BYTES + st_off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kr = min(kt * KT + st_row + 16 * i, p.L - 1);
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(vbase + (int64_t)kr * p.v_sl);
+            u32x4 hv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned w = raw[j];
+                hv[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(w << 16) * sc, __uint_as_float(w & 0xffff0000u) * sc));
+            }
+            *reinterpret_cast<u32x4*>(vd + i * 16 * 256) = hv;
         }
     };
 
@@ -194,18 +232,47 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     float m_run = -INFINITY, l_run = 0.f;
     const float c = p.c;
 
-    stage_load(items[it_begin * 2]);
-    stage_store(0);
+    // ---- software pipeline over the unit's items: the (tile, mask) pair of the NEXT tile is known one
+    // iteration ahead, so its K/V rows and mask words are requested before the current tile is computed, and
+    // the pair after that is fetched meanwhile.
+    int kt_cur = items[it_begin * 2], mi_cur = items[it_begin * 2 + 1];
+    int kt_nxt = 0, mi_nxt = -1;
+    if (it_begin + 1 < it_end) {
+        kt_nxt = items[(it_begin + 1) * 2];
+        mi_nxt = items[(it_begin + 1) * 2 + 1];
+    }
+    uint64_t mrow_cur = mi_cur >= 0 ? masks[(int64_t)mi_cur * RB + r] : ~0ull;
+    __syncthreads();  // vtag zeroed
+    stage_load(kt_cur);
+    stage_store(0, 1u);
     __syncthreads();
 
     int cur = 0;
     for (int it = it_begin; it < it_end; ++it) {
-        const int mask_idx = items[it * 2 + 1];
         const bool has_next = it + 1 < it_end;
-        if (has_next) stage_load(items[(it + 1) * 2]);
+        const unsigned seq = (unsigned)(it - it_begin) + 1u;
+        uint64_t mrow_nxt = ~0ull;
+        if (has_next) {
+            if (mi_nxt >= 0) mrow_nxt = masks[(int64_t)mi_nxt * RB + r];
+            stage_load(kt_nxt);
+        }
+        // unconditional (index clamped to the unit's last item) so that no branch copies the loaded registers
+        const int it2 = min(it + 2, it_end - 1);
+        int kt_nn = items[it2 * 2], mi_nn = items[it2 * 2 + 1];
 
         const unsigned char* kb_lds = smem + cur * TILE_BYTES;
         const unsigned char* vb_lds = smem + (2 + cur) * TILE_BYTES;
+
+        // ---- V tile beyond the fp16 range? (rare; workgroup-uniform)
+        int ve = 0;
+        {
+            const unsigned tg = vtag[cur];
+            if ((tg >> 8) == seq) ve = min((int)(tg & 0xffu) - 142, 15);
+        }
+        if (ve > 0) {
+            restage_v_scaled(cur, kt_cur, ve);
+            __syncthreads();
+        }
 
         // ---- S^T = K Q^T : two 32-key blocks
         f32x16 s0, s1;
@@ -221,10 +288,9 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         }
 
         // ---- mask: accumulator register i of block kb is key 32 kb + (i & 3) + 8 (i >> 2) + 4 h
-        if (mask_idx >= 0) {
-            const uint64_t mrow = masks[(int64_t)mask_idx * RB + r];
-            const unsigned lo = (unsigned)mrow >> (4 * h);
-            const unsigned hi = (unsigned)(mrow >> 32) >> (4 * h);
+        if (mi_cur >= 0) {
+            const unsigned lo = (unsigned)mrow_cur >> (4 * h);
+            const unsigned hi = (unsigned)(mrow_cur >> 32) >> (4 * h);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int bit = (i & 3) + 8 * (i >> 2);
@@ -241,28 +307,39 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         const float m_new = fmaxf(m_run, mx);
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = fast_exp2((m_run - m_safe) * c);
-        const float msc = m_safe * c;
+        const float nb = (float)ve - m_safe * c;  // probabilities carry 2^ve when V was scaled by 2^-ve
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            s0[i] = fast_exp2(__builtin_fmaf(s0[i], c, -msc));
-            s1[i] = fast_exp2(__builtin_fmaf(s1[i], c, -msc));
+            s0[i] = fast_exp2(__builtin_fmaf(s0[i], c, nb));
+            s1[i] = fast_exp2(__builtin_fmaf(s1[i], c, nb));
         }
 
-        // ---- P^T fragments: registers 8 s .. 8 s + 7 of block kb are k-step (kb, s) of the B operand.
-        // The row sum is taken over the bf16-rounded probabilities, the values the MFMA multiplies with, so
-        // that the output stays an exact convex combination of V rows: the rounding error of a dominant
-        // key then cancels against the normaliser instead of scaling the whole row.
-        bf16x8 pf[2][2];
-        float rs = 0.f;
+        // ---- P^T fragments in fp16: registers 8 s .. 8 s + 7 of block kb are k-step (kb, s) of the B operand.
+        // The row sum is taken over the ROUNDED probabilities, the values the MFMA multiplies with, so that
+        // the output stays an exact convex combination of V rows: the rounding error of a dominant key then
+        // cancels against the normaliser instead of scaling the whole row.
+        f16x8 pf[2][2];
+        float rs0 = 0.f, rs1 = 0.f;
+        const f16x2 ones = {(_Float16)1.0f, (_Float16)1.0f};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            pf[0][0][j] = (__bf16)s0[j];
-            pf[0][1][j] = (__bf16)s0[8 + j];
-            pf[1][0][j] = (__bf16)s1[j];
-            pf[1][1][j] = (__bf16)s1[8 + j];
-            rs += ((float)pf[0][0][j] + (float)pf[0][1][j]) + ((float)pf[1][0][j] + (float)pf[1][1][j]);
+        for (int j = 0; j < 4; ++j) {
+            f16x2 t;
+            t[0] = (_Float16)s0[2 * j]; t[1] = (_Float16)s0[2 * j + 1];
+            pf[0][0][2 * j] = t[0]; pf[0][0][2 * j + 1] = t[1];
+            rs0 = __builtin_amdgcn_fdot2(t, ones, rs0, false);
+            t[0] = (_Float16)s0[8 + 2 * j]; t[1] = (_Float16)s0[8 + 2 * j + 1];
+            pf[0][1][2 * j] = t[0]; pf[0][1][2 * j + 1] = t[1];
+            rs1 = __builtin_amdgcn_fdot2(t, ones, rs1, false);
+            t[0] = (_Float16)s1[2 * j]; t[1] = (_Float16)s1[2 * j + 1];
+            pf[1][0][2 * j] = t[0]; pf[1][0][2 * j + 1] = t[1];
+            rs0 = __builtin_amdgcn_fdot2(t, ones, rs0, false);
+            t[0] = (_Float16)s1[8 + 2 * j]; t[1] = (_Float16)s1[8 + 2 * j + 1];
+            pf[1][1][2 * j] = t[0]; pf[1][1][2 * j + 1] = t[1];
+            rs1 = __builtin_amdgcn_fdot2(t, ones, rs1, false);
         }
+        float rs = rs0 + rs1;
         rs += __shfl_xor(rs, 32);
+        if (ve > 0) rs *= __uint_as_float((unsigned)(127 - ve) << 23);
         l_run = l_run * alpha + rs;
         m_run = m_new;
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
@@ -284,17 +361,23 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
                         (__attribute__((address_space(3))) s16x4*)(vb_lds + rbase + v_off[db][0]));
                     const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) s16x4*)(vb_lds + rbase + 8 * 256 + v_off[db][1]));
-                    union { s16x4 hlf[2]; bf16x8 full; } va;
+                    union { s16x4 hlf[2]; f16x8 full; } va;
                     va.hlf[0] = a0;
                     va.hlf[1] = a1;
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.full, pf[kb][s], oacc[db], 0, 0, 0);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va.full, pf[kb][s], oacc[db], 0, 0, 0);
                 }
             }
         }
 
-        if (has_next) stage_store(cur ^ 1);
+        if (has_next) stage_store(cur ^ 1, seq + 1u);
         __syncthreads();
         cur ^= 1;
+        kt_cur = kt_nxt; mi_cur = mi_nxt; mrow_cur = mrow_nxt;
+        // The pair fetched above is consumed only now: keeping it opaque in vector registers until here stops
+        // the compiler from waiting for that load (and every load behind it) at the top of the iteration.
+        asm volatile("" : "+v"(kt_nn), "+v"(mi_nn));
+        kt_nxt = __builtin_amdgcn_readfirstlane(kt_nn);
+        mi_nxt = __builtin_amdgcn_readfirstlane(mi_nn);
     }
 
     if (!head_ok) return;

@@ -94,3 +94,29 @@ def test_dense_topk_bit_exact(N, d, nq, k):
     s, i = idx.search(Q, k)
     assert np.array_equal(i, ri)
     assert np.array_equal(s.view(np.uint32), rs.view(np.uint32))
+
+
+def test_attention_large_values_in_v():
+    """V magnitudes beyond the fp16 range (the P V product runs on fp16 operands) must still be exact to 1e-3."""
+    import sdag_amd
+    from oracle import sdag_ref
+
+    spans, qa, L = synthetic_layout(11, [70, 90, 50], 1, 20)
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(1, 4, L, 128, generator=g).to(torch.bfloat16)
+    k = torch.randn(1, 1, L, 128, generator=g).to(torch.bfloat16)
+    v = torch.randn(1, 1, L, 128, generator=g)
+    v[:, :, 64:128] *= 3.0e4      # one tile reaches ~1.2e5 > 65504
+    v[:, :, 130:140] *= 1.0e8     # and a few rows far beyond
+    v = v.to(torch.bfloat16)
+    mask = torch.from_numpy(sdag_ref.mask_from_spans(L, 11, spans, qa, None))
+    ref = sdag_ref.masked_attention(q, k, v, mask, 128 ** -0.5)
+    d = sdag_amd.from_spans(L, 11, spans, qa, None)
+    o = sdag_amd.sdag_attention(q.to(_dev()), k.to(_dev()), v.to(_dev()), d, out_dtype=torch.float32).cpu()
+    assert torch.isfinite(o).all()
+    # per row: rows that never see the huge values must not be polluted by them
+    num = (o - ref).abs().amax(dim=3)
+    den = ref.abs().amax(dim=3)
+    rel = float((num / den).max())
+    print("large-V per-row rel err", rel)
+    assert rel <= 1e-3

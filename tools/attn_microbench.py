@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Event-timed sweeps of sdag_attn_fwd over mask layouts and unit lengths (diagnostic, GPU only)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sparse-document-attention-rag-_amd")); sys.path.insert(0, ROOT)
+import numpy as np, torch
+import sdag_amd
+
+dev = torch.device("cuda:0")
+
+def layout(sys_len, n_docs, doc_len, gap, qa_len):
+    spans, pos = [], sys_len
+    for _ in range(n_docs):
+        spans.append((pos, pos + doc_len)); pos += doc_len + gap
+    return spans, pos, pos + qa_len
+
+def timeit(desc, L, Hq=32, Hkv=8, reps=20, nbuf=8):
+    D = 128
+    bufs = []
+    for i in range(nbuf):
+        q = torch.randn((1, L, Hq, D), device=dev).to(torch.bfloat16).transpose(1, 2)
+        k = torch.randn((1, L, Hkv, D), device=dev).to(torch.bfloat16).transpose(1, 2)
+        v = torch.randn((1, L, Hkv, D), device=dev).to(torch.bfloat16).transpose(1, 2)
+        o = torch.empty((1, L, Hq, D), device=dev, dtype=torch.bfloat16)
+        bufs.append(sdag_amd.BoundAttention(q, k, v, desc, o))
+    for c in bufs: c()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for r in range(reps):
+        for c in bufs: c()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (reps * nbuf)
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which == "one":
+        L = 4096
+        d = sdag_amd.from_spans(L, L, [], L, None, max_items_per_unit=100000)
+        print(f"causal L={L}: {timeit(d, L, reps=2, nbuf=2):.1f} us", flush=True)
+    if which in ("all", "causal"):
+        for L in (64, 512, 4096):
+            for T in (100000, 8):
+                d = sdag_amd.from_spans(L, L, [], L, None, max_items_per_unit=T)
+                print(f"causal L={L} T={T}: units={d.n_units} items={d.n_items} slots={d.n_slots} -> {timeit(d, L):.1f} us", flush=True)
+    if which in ("all", "cfg3"):
+        spans, qa, L = layout(60, 10, 300, 1, 30)
+        for T in (4, 6, 8, 11, 16, 32, 64):
+            d = sdag_amd.from_spans(L, 60, spans, qa, None, max_items_per_unit=T)
+            print(f"cfg3 T={T}: units={d.n_units} items={d.n_items} slots={d.n_slots} -> {timeit(d, L):.1f} us", flush=True)
+    if which in ("all", "cfg4"):
+        K = 20
+        spans, qa, L = layout(60, K, 380, 1, 30)
+        nbr = [[(i + 1) % K, (i + 2) % K] for i in range(K)]
+        for T in (8, 16, 32, 64):
+            d = sdag_amd.from_spans(L, 60, spans, qa, nbr, max_items_per_unit=T)
+            print(f"cfg4 T={T}: units={d.n_units} items={d.n_items} slots={d.n_slots} pairs={d.allowed_pairs} -> {timeit(d, L):.1f} us", flush=True)
