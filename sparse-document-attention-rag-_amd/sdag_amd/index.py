@@ -128,6 +128,16 @@ def unpack_partial(buf: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return buf[..., 0].to(torch.int32).view(torch.float32), buf[..., 1].contiguous()
 
 
+def gather_partials(mine: torch.Tensor, group=None) -> torch.Tensor:
+    """The one collective of the sharded search: all-gather of the packed [nq, k, 2] buffers -> [world, nq, k, 2]."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    flat = torch.empty((world * mine.shape[0],) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(flat, mine.contiguous(), group=group)
+    return flat.view((world,) + tuple(mine.shape))
+
+
 class ShardedFlatIPIndex:
     """Row-sharded exact search: local top-k with global ids -> one all-gather -> identical merge on every rank."""
 
@@ -155,10 +165,7 @@ class ShardedFlatIPIndex:
 
     def search_device(self, q: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
         s, i = self.local.search_device(q, k)
-        mine = pack_partial(s, i)
-        gathered = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
-        self.dist.all_gather_into_tensor(gathered, mine, group=self.group)
-        ps, pi = unpack_partial(gathered)
+        ps, pi = unpack_partial(gather_partials(pack_partial(s, i), self.group))
         return merge_partial_topk(ps, pi, k)
 
     def search(self, q, k: int) -> Tuple[np.ndarray, np.ndarray]:

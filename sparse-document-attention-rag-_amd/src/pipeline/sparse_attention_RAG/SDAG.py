@@ -1,0 +1,181 @@
+"""SDAG document-isolated generation on MI355X behind the reference's module surface
+(src/pipeline/sparse_attention_RAG/SDAG.py).
+
+Same public names, arguments and return values: ``compute_doc_knn_for_docs``,
+``build_blocked_causal_mask_full``, ``generate_with_custom_mask``, ``build_rag_chat_and_spans``,
+``run_rag_with_doc_isolation``.  What changes is underneath: the L x L mask is never built on the prefill
+path -- token spans become a block-sparse descriptor on the host in microseconds, and every attention layer of the
+prefill runs the HIP kernel driven by it.  ``build_blocked_causal_mask_full`` still returns the dense boolean
+tensor for callers that want it, expanded on the GPU from that same descriptor.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+import sdag_amd
+from sdag_amd import hf_attention
+
+try:  # frozen at import like the reference does (SDAG.py:9)
+    from src.pipeline.config import MAX_GEN_TOKENS_RAG, TEMPERATURE
+except Exception:  # pragma: no cover - standalone use
+    MAX_GEN_TOKENS_RAG, TEMPERATURE = 500, 0.1
+try:
+    from src.pipeline.utils.prompts import SYSTEM_PROMPT_RAG, USER_RAG_PROMPT
+except Exception:  # pragma: no cover - standalone use: the two templates the spans depend on (prompts.py:15,32-41)
+    SYSTEM_PROMPT_RAG = "You are a helpful assistant, below is a query from a user and some relevant contexts."
+    USER_RAG_PROMPT = ("Answer the question concisely, based on the following passages.\nKeep the answer concise.\n\n"
+                       "passages:\n{docs_text}\n\n- Question: {query}\n\n- Answer:\n")
+try:
+    from src.pipeline.utils.ranked_list import inject_malicious_docs_into_ranked_list
+except Exception:  # pragma: no cover - standalone use
+    from sdag_amd.ranked_list import inject_malicious_docs_into_ranked_list
+
+
+def _gpu_device(device) -> torch.device:
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        return dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cuda:0")  # kernels always run on the GPU; results are copied to `device` if it differs
+
+
+def compute_doc_knn_for_docs(ranker, docs: List[str], k_neighbors: int) -> List[List[int]]:
+    """k most similar other documents of each document, most similar first (SDAG.py:14-65).
+
+    Empty / whitespace documents are left out of the comparison and get [] (SDAG.py:42-44,51); fewer than two
+    non-empty documents, or k <= 0, give all-empty lists.  Texts are embedded with the "passage: " prefix
+    (SDAG.py:47); the Gram matrix is computed on the GPU.
+    """
+    n = len(docs)
+    if k_neighbors <= 0 or n == 0:
+        return [[] for _ in range(n)]
+    kept = [i for i, d in enumerate(docs) if d and d.strip()]
+    if len(kept) <= 1:
+        return [[] for _ in range(n)]
+    emb = ranker.encode(["passage: " + docs[i] for i in kept], convert_to_tensor=True, normalize_embeddings=True)
+    dev = emb.device if emb.is_cuda else torch.device("cuda:0")
+    return sdag_amd.doc_knn(emb.float(), kept, n, k_neighbors, device=dev)
+
+
+def build_blocked_causal_mask_full(base_seq_len: int, max_new_tokens: int, sys_user_len: int, doc_token_spans: list,
+                                   qa_start: int, device: str = "cpu", doc_neighbors: Optional[List[List[int]]] = None):
+    """Boolean [L, L] "row may attend column" tensor on ``device`` (SDAG.py:68-127).
+
+    ``max_new_tokens`` is accepted and unused, as in the reference.  The returned tensor remembers the
+    descriptor it was expanded from, so ``generate_with_custom_mask`` does not have to re-derive it.
+    """
+    desc = sdag_amd.from_spans(base_seq_len, sys_user_len, [tuple(s) for s in doc_token_spans], qa_start, doc_neighbors)
+    mask = desc.materialize(_gpu_device(device))
+    if mask.device != torch.device(device):
+        mask = mask.to(device)
+    mask._sdag_desc = desc
+    return mask
+
+
+def _descriptor_of(prompt_mask: torch.Tensor, model_dtype: torch.dtype) -> Optional[sdag_amd.Descriptor]:
+    desc = getattr(prompt_mask, "_sdag_desc", None)
+    if desc is not None and desc.L == prompt_mask.shape[0]:
+        return desc
+    if prompt_mask.dtype == torch.bool:
+        return sdag_amd.from_dense(prompt_mask)
+    # "pre-computed attention matrix" (SDAG.py:170-171): usable only if it is a 0 / very-negative additive mask
+    allowed = prompt_mask > torch.finfo(model_dtype).min / 2
+    if bool(((prompt_mask == 0) | ~allowed).all()):
+        return sdag_amd.from_dense(allowed)
+    return None
+
+
+def _sample(logits: torch.Tensor) -> torch.Tensor:
+    if TEMPERATURE > 0:  # SDAG.py:182-187
+        probs = torch.softmax(logits / TEMPERATURE, dim=-1)
+        return torch.multinomial(probs, num_samples=1)
+    return torch.argmax(logits, dim=-1, keepdim=True)
+
+
+def _decode_loop(model, tokenizer, input_ids, first_out, max_new_tokens: int) -> str:
+    """Sampling of the first token and the cached single-token steps, exactly as SDAG.py:178-213 (up to
+    max_new_tokens + 1 tokens; EOS is only tested inside the loop)."""
+    prompt_len = input_ids.size(1)
+    past = first_out.past_key_values
+    next_token = _sample(first_out.logits[:, -1, :])
+    generated = torch.cat([input_ids, next_token], dim=1)
+    for _ in range(max_new_tokens):
+        with torch.no_grad():
+            out = model(input_ids=generated[:, -1:], past_key_values=past, use_cache=True)
+        past = out.past_key_values
+        next_token = _sample(out.logits[:, -1, :])
+        generated = torch.cat([generated, next_token], dim=1)
+        if next_token.item() == tokenizer.eos_token_id:
+            break
+    return tokenizer.decode(generated[0][prompt_len:], skip_special_tokens=True).strip()
+
+
+def _generate_with_descriptor(model, tokenizer, input_ids, desc, max_new_tokens: int) -> str:
+    with hf_attention.use_on_model(model):
+        with torch.no_grad(), hf_attention.active_descriptor(desc):
+            out = model(input_ids=input_ids, use_cache=True)  # masked prefill: the kernel path
+        return _decode_loop(model, tokenizer, input_ids, out, max_new_tokens)
+
+
+def generate_with_custom_mask(model, tokenizer, input_ids: torch.Tensor, prompt_mask: torch.Tensor,
+                              max_new_tokens: int = 128):
+    """Prefill under ``prompt_mask`` (bool [L, L], True = attend), then ordinary cached decoding (SDAG.py:130-213)."""
+    model_dtype = next(model.parameters()).dtype
+    desc = _descriptor_of(prompt_mask, model_dtype)
+    if desc is None:  # a general additive float mask: not expressible as allow / forbid, run it the stock way
+        attn = prompt_mask.to(input_ids.device, dtype=model_dtype).unsqueeze(0).unsqueeze(1)
+        with torch.no_grad():
+            out = model(input_ids=input_ids, attention_mask=attn, use_cache=True)
+        return _decode_loop(model, tokenizer, input_ids, out, max_new_tokens)
+    return _generate_with_descriptor(model, tokenizer, input_ids, desc, max_new_tokens)
+
+
+def _n_tokens(tokenizer, text: str) -> int:
+    return len(tokenizer(text, return_tensors="pt").input_ids[0])
+
+
+def build_rag_chat_and_spans(tokenizer, system_prompt: str, user_template: str, query: str, malicious_docs: List[str],
+                             retrieved_docs: list, add_attack_in_rank: int):
+    """Prompt string and the token spans of its parts (SDAG.py:216-304).
+
+    Returns (chat_str, sys_user_len, doc_token_spans, qa_start, ranked_docs).  Token positions are those of
+    prefix tokenisations of ``chat_str`` -- the length in tokens of the text before each boundary -- which is how
+    the reference defines them (SDAG.py:289-302).
+    """
+    ranked_docs = inject_malicious_docs_into_ranked_list(base_docs=retrieved_docs, malicious_docs=malicious_docs,
+                                                         attack_pos=add_attack_in_rank)
+    bullets = [f"- {d.strip()}" for d in ranked_docs if d and d.strip()]
+    user_content = user_template.format(query=query, docs_text="\n\n".join(bullets))
+    chat_str = tokenizer.apply_chat_template(
+        [{"role": "system", "content": system_prompt}, {"role": "user", "content": user_content}],
+        tokenize=False, add_generation_prompt=True)
+
+    starts, cursor = [], 0
+    for text in bullets:  # first occurrence at or after the previous bullet; a miss stays at the cursor (SDAG.py:277-282)
+        at = chat_str.find(text, cursor)
+        at = cursor if at == -1 else at
+        starts.append(at)
+        cursor = at + len(text)
+    q_at = chat_str.find("- Question:")
+    q_at = len(chat_str) if q_at == -1 else q_at
+
+    sys_user_len = _n_tokens(tokenizer, chat_str[: starts[0] if starts else q_at])
+    spans = [(_n_tokens(tokenizer, chat_str[:at]), _n_tokens(tokenizer, chat_str[: at + len(text)]))
+             for text, at in zip(bullets, starts)]
+    qa_start = _n_tokens(tokenizer, chat_str[:q_at])
+    return chat_str, sys_user_len, spans, qa_start, ranked_docs
+
+
+def run_rag_with_doc_isolation(model, tokenizer, query: str, malicious_docs: List[str], retrieved_docs: list,
+                               max_new_tokens: int, device: str, add_attack_in_rank: int, ranker, doc_neighbors_k: int):
+    """Answer ``query`` over the ranked documents with document-isolated attention (SDAG.py:307-375)."""
+    chat_str, sys_user_len, spans, qa_start, ranked_docs = build_rag_chat_and_spans(
+        tokenizer=tokenizer, system_prompt=SYSTEM_PROMPT_RAG, user_template=USER_RAG_PROMPT, query=query,
+        malicious_docs=malicious_docs, retrieved_docs=retrieved_docs, add_attack_in_rank=add_attack_in_rank)
+    neighbors = None
+    if doc_neighbors_k and doc_neighbors_k > 0:
+        neighbors = compute_doc_knn_for_docs(ranker=ranker, docs=ranked_docs, k_neighbors=doc_neighbors_k)
+    input_ids = tokenizer(chat_str, return_tensors="pt").to(device)["input_ids"]
+    desc = sdag_amd.from_spans(input_ids.size(1), sys_user_len, spans, qa_start, neighbors)
+    return _generate_with_descriptor(model, tokenizer, input_ids, desc, max_new_tokens=max_new_tokens)

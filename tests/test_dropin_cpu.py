@@ -1,0 +1,202 @@
+"""Host logic of the drop-in modules, on CPU.  Where a step needs the GPU kernel, the test substitutes the CPU
+oracle for it (the oracle is the checker here; the product modules never import it)."""
+import importlib
+import json
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, expand_descriptor
+from oracle import sdag_ref
+
+
+@pytest.fixture()
+def SDAG():
+    return importlib.import_module("src.pipeline.sparse_attention_RAG.SDAG")
+
+
+def test_module_surface_matches_reference_names(SDAG):
+    for name in ("compute_doc_knn_for_docs", "build_blocked_causal_mask_full", "generate_with_custom_mask",
+                 "build_rag_chat_and_spans", "run_rag_with_doc_isolation"):
+        assert callable(getattr(SDAG, name))
+    alias = importlib.import_module("src.pipeline.sdag")
+    assert alias.run_rag_with_doc_isolation is SDAG.run_rag_with_doc_isolation
+    dense = importlib.import_module("src.pipeline.retrieval.dense")
+    for name in ("load_faiss_index_and_meta", "embed_queries", "search_index", "materialize_dense_hits", "DenseRetriever"):
+        assert hasattr(dense, name)
+    retr = importlib.import_module("src.pipeline.retrieval.retriever")
+    assert issubclass(dense.DenseRetriever, retr.Retriever)
+    with pytest.raises(TypeError):
+        retr.Retriever()  # abstract
+
+
+class ToyTokenizer:
+    """Whitespace-and-punctuation tokenizer with a chat template: enough for span extraction."""
+    eos_token_id = 2
+
+    def apply_chat_template(self, messages, tokenize=False, add_generation_prompt=True):
+        s = "<s>"
+        for m in messages:
+            s += f"[{m['role']}]\n{m['content']}</e>\n"
+        return s + "[assistant]\n"
+
+    def _split(self, text):
+        import re
+        return re.findall(r"\w+|[^\w\s]|\s+", text)
+
+    def __call__(self, text, return_tensors="pt"):
+        ids = torch.tensor([[hash(t) % 200 + 3 for t in self._split(text)]])
+
+        class Enc(dict):
+            def to(self, device):
+                return self
+        e = Enc(input_ids=ids)
+        e.input_ids = ids
+        return e
+
+    def decode(self, ids, skip_special_tokens=True):
+        return " ".join(str(int(i)) for i in ids)
+
+
+def test_build_rag_chat_and_spans_semantics(SDAG):
+    tok = ToyTokenizer()
+    docs = ["alpha beta gamma", "", "delta epsilon", "  ", "zeta"]
+    chat, sys_len, spans, qa, ranked = SDAG.build_rag_chat_and_spans(tok, "SYS", SDAG.USER_RAG_PROMPT, "what is x?", ["EVIL doc"], docs, 2)
+    assert ranked == ["alpha beta gamma", "EVIL doc", "", "delta epsilon", "  ", "zeta"]   # injected at rank 2
+    assert len(spans) == 4                                                                 # empty documents have no bullet
+    n = lambda s: len(tok(s).input_ids[0])
+    pos = 0
+    for (s, e), text in zip(spans, ["- alpha beta gamma", "- EVIL doc", "- delta epsilon", "- zeta"]):
+        at = chat.find(text, pos)
+        assert (s, e) == (n(chat[:at]), n(chat[:at + len(text)]))
+        pos = at + len(text)
+    assert sys_len == spans[0][0] and qa == n(chat[:chat.find("- Question:")])
+    # no documents at all: the system/user section runs up to the question marker
+    chat, sys_len, spans, qa, _ = SDAG.build_rag_chat_and_spans(tok, "SYS", SDAG.USER_RAG_PROMPT, "q", [], [], 0)
+    assert spans == [] and sys_len == qa
+
+
+def test_ranked_list_injection_rules():
+    from sdag_amd.ranked_list import inject_malicious_docs_into_ranked_list as inj
+
+    base = ["a", "b", "c"]
+    assert inj(base, [], 1) == base and inj(base, ["x"], 0) == base
+    assert inj(base, ["x", "y"], 2) == ["a", "x", "y", "b", "c"]
+    assert inj(base, ["x"], 99) == ["a", "b", "c", "x"]
+    assert inj(base, ["x"], -5) == base
+    assert inj(base, ["x", "y"], [3, 1]) == ["y", "a", "b", "x", "c"]
+    assert inj(base, ["x", "y"], [None, 2]) == ["a", "y", "b", "c"]
+    random.seed(0)
+    out = inj(base, ["x", "y"], [1])            # the missing position is padded with "random"
+    assert out[0] == "x" and sorted(out) == ["a", "b", "c", "x", "y"]
+    random.seed(1)
+    assert sorted(inj(base, ["x"], -1)) == ["a", "b", "c", "x"]
+
+
+def test_materialize_and_search_order():
+    dense = importlib.import_module("src.pipeline.retrieval.dense")
+    with open(f"{GOLDEN}/small_ops.json") as f:
+        h = json.load(f)["hits"]
+    out = dense.materialize_dense_hits(h["idx"], h["sc"], h["meta"])
+    assert [list(x) for x in out] == h["out"]
+
+    class FakeIndex:
+        def search(self, q, k):
+            assert q.dtype == np.float32
+            return np.full((len(q), k), 0.5, np.float32), np.arange(len(q) * k, dtype=np.int64).reshape(len(q), k)
+
+    ind, sc = dense.search_index(FakeIndex(), np.ones((2, 4), np.float64), 3)
+    assert ind.dtype == np.int64 and sc.dtype == np.float32
+
+    class FakeRanker:
+        def encode(self, texts, convert_to_tensor=True, batch_size=32, normalize_embeddings=True):
+            assert all(t.startswith("query: ") for t in texts)     # e5 prefix (dense.py:59)
+            return torch.ones(len(texts), 4)
+
+    r = dense.DenseRetriever(FakeRanker(), FakeIndex(), [{"id": i, "text": f"t{i}"} for i in range(4)])
+    rb = r.retrieve_batch(["q1", "q2", "q3"], 3, 2)
+    assert len(rb.q_embs) == 3 and rb.ids_full[0] == ["0", "1", "2"] and rb.ids_full[1] == ["3", "NA", "NA"]
+    assert rb.docs_texts_full[1] == ["t3", "", ""] and rb.scores_full[2] == [0.5, 0.5, 0.5]
+
+
+def test_flat_index_file_round_trip(tmp_path):
+    from sdag_amd import index_io
+
+    x = np.random.default_rng(0).standard_normal((37, 64)).astype(np.float32)
+    p = str(tmp_path / "flat.index")
+    index_io.write_flat_ip(p, x)
+    assert np.array_equal(np.asarray(index_io.read_flat_vectors(p)), x)
+    np.save(str(tmp_path / "c.npy"), x)
+    assert np.array_equal(np.asarray(index_io.read_flat_vectors(str(tmp_path / "c.npy"))), x)
+    dense = importlib.import_module("src.pipeline.retrieval.dense")
+    with pytest.raises(FileNotFoundError, match="FAISS index not found"):
+        dense.load_faiss_index_and_meta(str(tmp_path / "missing"), str(tmp_path / "c.npy"))
+    with pytest.raises(FileNotFoundError, match="Metadata jsonl not found"):
+        dense.load_faiss_index_and_meta(p, str(tmp_path / "missing.jsonl"))
+    (tmp_path / "bad.index").write_bytes(b"IxF2" + b"\0" * 64)
+    with pytest.raises(NotImplementedError):
+        index_io.read_flat_vectors(str(tmp_path / "bad.index"))
+
+
+def _tiny_llama():
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    z = np.load(f"{GOLDEN}/tiny_llama.npz")
+    meta = json.loads(bytes(z["meta"]).decode())
+    cfg = LlamaConfig(**meta["cfg"])
+    model = LlamaForCausalLM(cfg).eval()
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w::")}
+    model.load_state_dict(sd)
+    return model, z, meta
+
+
+def test_generate_through_hf_hook_matches_reference_greedy_text(SDAG, monkeypatch):
+    """Prompt -> descriptor -> transformers attention hook -> decode loop, with the oracle standing in for the
+    HIP kernel: prefill logits and greedy text equal what the reference's generate_with_custom_mask produced."""
+    from sdag_amd import hf_attention
+    import sdag_amd
+
+    model, z, meta = _tiny_llama()
+    c = meta["case"]
+    calls = {"prefill": 0}
+
+    def oracle_attention(q, k, v, desc, scaling=None, out_dtype=torch.bfloat16, out=None):
+        calls["prefill"] += 1
+        mask = torch.from_numpy(expand_descriptor(desc.host))
+        return sdag_ref.masked_attention(q.float(), k.float(), v.float(), mask, scaling)
+
+    monkeypatch.setattr(hf_attention, "sdag_attention", oracle_attention)
+    monkeypatch.setattr(hf_attention.torch, "bfloat16", torch.float32, raising=False)  # keep the fp32 model in fp32
+    monkeypatch.setattr(SDAG, "TEMPERATURE", 0)
+
+    class Tok:
+        eos_token_id = 2
+
+        def decode(self, t, skip_special_tokens=True):
+            return " ".join(str(int(i)) for i in t)
+
+    ids = torch.from_numpy(z["input_ids"])
+    desc = sdag_amd.from_spans(c["L"], c["sys"], c["spans"], c["qa"], c["nbr"])
+    seen = {}
+    orig = model.forward
+
+    def spy(*a, **kw):
+        o = orig(*a, **kw)
+        seen.setdefault("logits", o.logits[:, -1, :].detach().clone())
+        return o
+
+    model.forward = spy
+    before = model.config._attn_implementation
+    text = SDAG._generate_with_descriptor(model, Tok(), ids, desc, max_new_tokens=meta["max_new_tokens"])
+    assert model.config._attn_implementation == before            # restored
+    assert calls["prefill"] == meta["cfg"]["num_hidden_layers"]   # the kernel path ran once per layer, decode did not use it
+    ref_logits = torch.from_numpy(z["prefill_last_logits"])
+    assert torch.allclose(seen["logits"], ref_logits, atol=1e-4, rtol=1e-4)
+    assert text == bytes(z["greedy_text"]).decode()
+    assert len(text.split()) == meta["max_new_tokens"] + 1       # the reference's off-by-one is kept
+    # a bool mask without an attached descriptor goes through from_dense and gives the same text
+    mask = torch.from_numpy(sdag_ref.mask_from_spans(c["L"], c["sys"], c["spans"], c["qa"], c["nbr"]))
+    model.forward = orig
+    assert SDAG.generate_with_custom_mask(model, Tok(), ids, mask, max_new_tokens=meta["max_new_tokens"]) == text

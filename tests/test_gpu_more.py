@@ -1,0 +1,283 @@
+"""GPU parity: drop-in modules, merge / sharded search, small ops, and full-size cases."""
+import hashlib
+import importlib
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, golden_bits, load_masks, synthetic_layout
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel_err(o, ref):
+    num = (o - ref).abs().amax(dim=(0, 1, 3))
+    den = ref.abs().amax(dim=(0, 1, 3))
+    return float((num / den).max())
+
+
+def test_build_blocked_causal_mask_full_dropin():
+    SDAG = importlib.import_module("src.pipeline.sparse_attention_RAG.SDAG")
+    for c in load_masks()["small"][:12]:
+        m = SDAG.build_blocked_causal_mask_full(c["L"], 500, c["sys"], [tuple(s) for s in c["spans"]], c["qa"],
+                                                device=DEV, doc_neighbors=c["nbr"])
+        assert m.dtype == torch.bool and m.is_cuda and tuple(m.shape) == (c["L"], c["L"])
+        assert np.array_equal(m.cpu().numpy(), golden_bits(c))
+    m = SDAG.build_blocked_causal_mask_full(12, 500, 3, [(3, 5), (6, 9)], 10)   # default device="cpu"
+    assert m.device.type == "cpu" and not m[5].any() and m[3, 6:9].sum() == 0
+
+
+def test_attention_cfg4_neighbours_full_size():
+    import sdag_amd
+    from oracle import sdag_ref
+
+    K = 20
+    spans, qa, L = synthetic_layout(60, [380] * K, 1, 30)
+    nbr = [[(i + 1) % K, (i + 2) % K] for i in range(K)]
+    g = torch.Generator().manual_seed(1)
+    q = torch.randn(1, 4, L, 128, generator=g).to(torch.bfloat16)
+    k = torch.randn(1, 1, L, 128, generator=g).to(torch.bfloat16)
+    v = torch.randn(1, 1, L, 128, generator=g).to(torch.bfloat16)
+    mask = torch.from_numpy(sdag_ref.mask_from_spans(L, 60, spans, qa, nbr))
+    ref = sdag_ref.masked_attention(q, k, v, mask, 128 ** -0.5)
+    d = sdag_amd.from_spans(L, 60, spans, qa, nbr)
+    o = sdag_amd.sdag_attention(q.to(DEV), k.to(DEV), v.to(DEV), d, out_dtype=torch.float32).cpu()
+    err = _rel_err(o, ref)
+    print("cfg4 rel err", err)
+    assert err <= 1e-3
+
+
+@pytest.mark.parametrize("Hq,Hkv,B", [(1, 1, 2), (2, 1, 1), (8, 8, 1), (16, 2, 2), (3, 1, 1)])
+def test_attention_head_layouts_batch_and_strides(Hq, Hkv, B):
+    """MHA / GQA ratios that do not fill a workgroup, batch > 1, and the transposed views transformers passes."""
+    import sdag_amd
+    from oracle import sdag_ref
+
+    spans, qa, L = synthetic_layout(9, [40, 0, 75, 33], 2, 17)
+    nbr = [[2], [0], [3, 0], [1]]
+    g = torch.Generator().manual_seed(Hq * 10 + Hkv)
+    q = torch.randn(B, L, Hq, 128, generator=g).to(torch.bfloat16).transpose(1, 2)     # [B, Hq, L, D] view
+    k = torch.randn(B, L, Hkv, 128, generator=g).to(torch.bfloat16).transpose(1, 2)
+    v = torch.randn(B, Hkv, L, 128, generator=g).to(torch.bfloat16)                    # contiguous heads-first
+    mask = torch.from_numpy(sdag_ref.mask_from_spans(L, 9, spans, qa, nbr))
+    ref = sdag_ref.masked_attention(q, k, v, mask, 0.11)
+    d = sdag_amd.from_spans(L, 9, spans, qa, nbr, max_items_per_unit=2)                # force split units + merge
+    o = sdag_amd.sdag_attention(q.to(DEV), k.to(DEV), v.to(DEV), d, scaling=0.11, out_dtype=torch.float32).cpu()
+    assert _rel_err(o, ref) <= 1e-3
+
+
+def test_attention_arbitrary_dense_mask_and_spike():
+    """from_dense descriptors (random masks) and a score spike that forces the online-softmax rescale late."""
+    import sdag_amd
+    from oracle import sdag_ref
+
+    L = 300
+    rng = np.random.default_rng(3)
+    m = rng.random((L, L)) < 0.2
+    m[17] = False
+    m[:, 250:260] |= rng.random((L, 10)) < 0.9
+    g = torch.Generator().manual_seed(9)
+    q = torch.randn(1, 4, L, 128, generator=g)
+    k = torch.randn(1, 1, L, 128, generator=g)
+    v = torch.randn(1, 1, L, 128, generator=g)
+    k[0, 0, 255] = q[0, 1, 40] * 3.0          # one key aligned with one query: a late, large maximum
+    q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+    ref = sdag_ref.masked_attention(q, k, v, torch.from_numpy(m), 128 ** -0.5)
+    d = sdag_amd.from_dense(m)
+    o = sdag_amd.sdag_attention(q.to(DEV), k.to(DEV), v.to(DEV), d, out_dtype=torch.float32).cpu()
+    assert torch.isfinite(o).all() and _rel_err(o, ref) <= 1e-3
+
+
+def test_merge_and_simulated_shards():
+    import sdag_amd
+    from oracle import dense_ref
+
+    rng = np.random.default_rng(11)
+    N, d, nq, k = 30_000, 256, 19, 10
+    C = rng.standard_normal((N, d), dtype=np.float32)
+    Q = rng.standard_normal((nq, d), dtype=np.float32)
+    parts_s, parts_i = [], []
+    for r in range(8):
+        lo, hi = sdag_amd.shard_bounds(N, 8, r)
+        idx = sdag_amd.FlatIPIndex(d, device=DEV, id_base=lo)
+        idx.add(C[lo:hi])
+        s, i = idx.search_device(torch.from_numpy(Q), k)
+        parts_s.append(s)
+        parts_i.append(i)
+    ms, mi = sdag_amd.merge_partial_topk(torch.stack(parts_s), torch.stack(parts_i), k)
+    gs, gi = dense_ref.dense_topk(Q, C, k)
+    assert np.array_equal(mi.cpu().numpy(), gi) and np.array_equal(ms.cpu().numpy().view(np.uint32), gs.view(np.uint32))
+    # empty and tiny shards keep the fill convention
+    idx = sdag_amd.FlatIPIndex(d, device=DEV)
+    s, i = idx.search(Q, k)
+    assert (i == -1).all() and (s == -np.finfo(np.float32).max).all()
+
+
+def test_dense_topk_full_corpus_properties():
+    """2,000,000 x 1024 corpus: ids/scores of the GPU search re-scored by the oracle, nothing outside beats the
+    k-th score on a 200,000-row sample, and the search equals the merge of 8 shard searches."""
+    import sdag_amd
+    from oracle import dense_ref
+
+    N, d, nq, k = 2_000_000, 1024, 32, 10
+    g = torch.Generator(device=DEV).manual_seed(0)
+    C = torch.empty((N, d), device=DEV)
+    for lo in range(0, N, 1 << 18):
+        hi = min(N, lo + (1 << 18))
+        x = torch.randn((hi - lo, d), generator=g, device=DEV)
+        C[lo:hi] = x / x.norm(dim=1, keepdim=True)
+    Q = torch.randn((nq, d), generator=g, device=DEV)
+    Q = Q / Q.norm(dim=1, keepdim=True)
+    idx = sdag_amd.FlatIPIndex(d, device=DEV)
+    idx._corpus = C
+    s, i = idx.search_device(Q, k)
+    s2, i2 = idx.search_device(Q, k)
+    assert torch.equal(i, i2) and torch.equal(s, s2)                      # deterministic
+    sh, ih = s.cpu().numpy(), i.cpu().numpy()
+    assert (np.diff(sh, axis=1) <= 0).all() and (ih >= 0).all() and (ih < N).all()
+    Qh = Q.cpu().numpy()
+    rows = np.unique(ih)
+    sc = dense_ref.dense_scores(Qh, C[torch.from_numpy(rows).to(DEV)].cpu().numpy())   # [rows, nq]
+    pos = {int(r): n for n, r in enumerate(rows)}
+    for qi in range(nq):
+        exact = np.array([sc[pos[int(r)], qi] for r in ih[qi]], dtype=np.float32)
+        assert np.array_equal(exact.view(np.uint32), sh[qi].view(np.uint32))
+    sample = torch.arange(0, N, 10, device=DEV)
+    rs, ri = dense_ref.dense_topk(Qh, C[sample].cpu().numpy(), k)
+    assert (rs[:, 0] <= sh[:, 0]).all() and (rs[:, -1] <= sh[:, -1]).all()
+    for qi in range(nq):                                                  # sampled rows that belong in the top-k are there
+        for sc_, id_ in zip(rs[qi], ri[qi]):
+            gid = int(sample[id_])
+            if sc_ > sh[qi, -1]:
+                assert gid in ih[qi]
+    parts = []
+    for r in range(8):
+        lo, hi = sdag_amd.shard_bounds(N, 8, r)
+        sub = sdag_amd.FlatIPIndex(d, device=DEV, id_base=lo)
+        sub._corpus = C[lo:hi]
+        parts.append(sub.search_device(Q, k))
+    ms, mi = sdag_amd.merge_partial_topk(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), k)
+    assert torch.equal(mi, i) and torch.equal(ms, s)
+
+
+class FakeRanker:
+    def __init__(self, d=64, device="cpu"):
+        self.d, self.device = d, device
+
+    def get_sentence_embedding_dimension(self):
+        return self.d
+
+    def encode(self, texts, convert_to_tensor=True, normalize_embeddings=True, batch_size=32):
+        rows = []
+        for t in texts:
+            seed = int.from_bytes(hashlib.sha256(t.encode()).digest()[:4], "little")
+            v = np.random.default_rng(seed).standard_normal(self.d).astype(np.float32)
+            rows.append(v / np.linalg.norm(v))
+        return torch.from_numpy(np.stack(rows)).to(self.device)
+
+
+def test_doc_knn_and_centroid_against_reference_outputs():
+    import sdag_amd
+    SDAG = importlib.import_module("src.pipeline.sparse_attention_RAG.SDAG")
+    with open(f"{GOLDEN}/small_ops.json") as f:
+        g = json.load(f)
+    for dev in ("cpu", DEV):
+        rk = FakeRanker(g["ranker_dim"], dev)
+        for c in g["knn"]:
+            assert SDAG.compute_doc_knn_for_docs(rk, c["docs"], c["k"]) == c["out"]
+    rk = FakeRanker(g["ranker_dim"])
+    for c in g["select"]:
+        kept = [t for t in c["retrieved"] if t and t.strip()]
+        r = rk.encode(["passage: " + t for t in kept])
+        cand = rk.encode(["passage: " + t for t in c["cands"]])
+        sims = sdag_amd.centroid_sims(r, cand, device=DEV).cpu().numpy()
+        order = np.argsort(-sims) if c["strategy"] == "closest_to_centroid" else np.argsort(sims)
+        n = len(c["out"])
+        assert [c["cands"][int(j)] for j in order[:n]] == c["out"]
+
+
+def test_dense_retriever_end_to_end(tmp_path):
+    import sdag_amd
+    from sdag_amd import index_io
+    from oracle import dense_ref
+    dense = importlib.import_module("src.pipeline.retrieval.dense")
+
+    rk = FakeRanker(64)
+    docs = [f"passage number {i}" for i in range(500)]
+    emb = rk.encode(["passage: " + t for t in docs]).numpy()
+    index_io.write_flat_ip(str(tmp_path / "faiss.index"), emb)
+    with open(tmp_path / "meta.jsonl", "w") as f:
+        for i, t in enumerate(docs):
+            f.write(json.dumps({"id": 1000 + i, "text": t}) + "\n")
+    index, meta = dense.load_faiss_index_and_meta(str(tmp_path / "faiss.index"), str(tmp_path / "meta.jsonl"), device=DEV)
+    assert index.ntotal == 500 and len(meta) == 500
+    r = dense.DenseRetriever(rk, index, meta)
+    queries = [f"question {i}" for i in range(5)]
+    rb = r.retrieve_batch(queries, 11, 2)
+    qe = rk.encode(["query: " + q for q in queries]).numpy()
+    rs, ri = dense_ref.dense_topk(qe, emb, 11)
+    assert rb.ids_full == [[str(1000 + int(j)) for j in row] for row in ri]
+    assert rb.docs_texts_full[0][0] == docs[int(ri[0, 0])]
+    assert np.array_equal(np.asarray(rb.scores_full, dtype=np.float32).view(np.uint32), rs.view(np.uint32))
+    rb = r.retrieve_batch(queries[:1], 11, 8)
+    assert len(rb.ids_full[0]) == 11
+
+
+def _tiny_llama(dtype):
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    z = np.load(f"{GOLDEN}/tiny_llama.npz")
+    meta = json.loads(bytes(z["meta"]).decode())
+    model = LlamaForCausalLM(LlamaConfig(**meta["cfg"])).eval()
+    model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w::")})
+    return model.to(DEV, dtype=dtype), z, meta
+
+
+def test_generate_with_custom_mask_on_gpu():
+    """Tiny Llama (weights from the golden file): the kernel path through transformers vs (a) the reference's own
+    fp32 prefill logits and greedy text, and (b) the dense-additive-mask eager path on the same device and dtype."""
+    SDAG = importlib.import_module("src.pipeline.sparse_attention_RAG.SDAG")
+    from oracle import sdag_ref
+
+    class Tok:
+        eos_token_id = 2
+
+        def decode(self, t, skip_special_tokens=True):
+            return " ".join(str(int(i)) for i in t)
+
+    old_t = SDAG.TEMPERATURE
+    SDAG.TEMPERATURE = 0
+    try:
+        for dtype, tol in ((torch.float32, 2e-2), (torch.bfloat16, 6e-2)):
+            model, z, meta = _tiny_llama(dtype)
+            c = meta["case"]
+            ids = torch.from_numpy(z["input_ids"]).to(DEV)
+            mask = SDAG.build_blocked_causal_mask_full(c["L"], 500, c["sys"], [tuple(s) for s in c["spans"]], c["qa"],
+                                                       device=DEV, doc_neighbors=c["nbr"])
+            seen = {}
+            orig = model.forward
+
+            def spy(*a, **kw):
+                o = orig(*a, **kw)
+                seen.setdefault("logits", o.logits[:, -1, :].detach().float().cpu())
+                return o
+
+            model.forward = spy
+            text = SDAG.generate_with_custom_mask(model, Tok(), ids, mask, max_new_tokens=meta["max_new_tokens"])
+            model.forward = orig
+            ref_logits = torch.from_numpy(z["prefill_last_logits"])
+            scale = float(ref_logits.abs().max())
+            assert float((seen["logits"] - ref_logits).abs().max()) <= tol * scale
+            # the reference path restated on this device: eager attention under the dense additive mask
+            model.config._attn_implementation = "eager"
+            add = sdag_ref.additive_mask(mask.cpu(), dtype).to(DEV)
+            with torch.no_grad():
+                eager = model(input_ids=ids, attention_mask=add, use_cache=True).logits[:, -1, :].float().cpu()
+            assert float((seen["logits"] - eager).abs().max()) <= tol * scale
+            if dtype == torch.float32:
+                assert text == bytes(z["greedy_text"]).decode()
+    finally:
+        SDAG.TEMPERATURE = old_t

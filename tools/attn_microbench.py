@@ -14,14 +14,14 @@ def layout(sys_len, n_docs, doc_len, gap, qa_len):
         spans.append((pos, pos + doc_len)); pos += doc_len + gap
     return spans, pos, pos + qa_len
 
-def timeit(desc, L, Hq=32, Hkv=8, reps=20, nbuf=8):
+def timeit(desc, L, Hq=32, Hkv=8, reps=20, nbuf=8, B=1):
     D = 128
     bufs = []
     for i in range(nbuf):
-        q = torch.randn((1, L, Hq, D), device=dev).to(torch.bfloat16).transpose(1, 2)
-        k = torch.randn((1, L, Hkv, D), device=dev).to(torch.bfloat16).transpose(1, 2)
-        v = torch.randn((1, L, Hkv, D), device=dev).to(torch.bfloat16).transpose(1, 2)
-        o = torch.empty((1, L, Hq, D), device=dev, dtype=torch.bfloat16)
+        q = torch.randn((B, L, Hq, D), device=dev).to(torch.bfloat16).transpose(1, 2)
+        k = torch.randn((B, L, Hkv, D), device=dev).to(torch.bfloat16).transpose(1, 2)
+        v = torch.randn((B, L, Hkv, D), device=dev).to(torch.bfloat16).transpose(1, 2)
+        o = torch.empty((B, L, Hq, D), device=dev, dtype=torch.bfloat16)
         bufs.append(sdag_amd.BoundAttention(q, k, v, desc, o))
     for c in bufs: c()
     torch.cuda.synchronize()
@@ -38,6 +38,13 @@ if __name__ == "__main__":
         L = 4096
         d = sdag_amd.from_spans(L, L, [], L, None, max_items_per_unit=100000)
         print(f"causal L={L}: {timeit(d, L, reps=2, nbuf=2):.1f} us", flush=True)
+    if which == "batch":
+        spans, qa, L = layout(60, 10, 300, 1, 30)
+        for B in (1, 2, 4, 8, 16, 32):
+            for T in (11, 64):
+                d = sdag_amd.from_spans(L, 60, spans, qa, None, max_items_per_unit=T)
+                t = timeit(d, L, reps=5, nbuf=2, B=B)
+                print(f"cfg3 B={B} T={T}: {t:.1f} us/launch = {t / B:.1f} us/query-layer", flush=True)
     if which in ("all", "causal"):
         for L in (64, 512, 4096):
             for T in (100000, 8):
