@@ -200,3 +200,26 @@ def test_generate_through_hf_hook_matches_reference_greedy_text(SDAG, monkeypatc
     mask = torch.from_numpy(sdag_ref.mask_from_spans(c["L"], c["sys"], c["spans"], c["qa"], c["nbr"]))
     model.forward = orig
     assert SDAG.generate_with_custom_mask(model, Tok(), ids, mask, max_new_tokens=meta["max_new_tokens"]) == text
+
+
+def test_overlay_on_reference_tree_when_present():
+    """With this package in front of the reference on the path, the two hot-path modules resolve here and
+    everything else (config, data models, utils) stays the reference's.  Skipped where the reference is absent."""
+    import os
+    import subprocess
+    import sys
+
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "src", "pipeline")):
+        pytest.skip("reference tree not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "sparse-document-attention-rag-_amd")
+    code = (
+        "import src.pipeline.retrieval.dense as d, src.pipeline.config as c, src.pipeline.sparse_attention_RAG.SDAG as S;"
+        "import src.pipeline.models.datamodels as dm; from sdag_amd.datamodels import RetrievalBatch;"
+        "print(d.__file__); print(S.__file__); print(c.__file__); print(RetrievalBatch is dm.RetrievalBatch)")
+    env = dict(os.environ, PYTHONPATH=f"{pkg}:{ref}", PYTHONDONTWRITEBYTECODE="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd="/tmp", timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0].startswith(pkg) and lines[1].startswith(pkg) and lines[2].startswith(ref) and lines[3] == "True"
