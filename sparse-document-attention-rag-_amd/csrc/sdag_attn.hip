@@ -27,6 +27,9 @@
 #include "common.h"
 
 namespace sdag {
+#ifdef SDAG_STAMPS
+__device__ unsigned long long g_stamps[16];
+#endif
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -36,6 +39,7 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 constexpr int D = 128;            // head dim
@@ -73,7 +77,51 @@ __device__ __forceinline__ int tile_off(int row, int ch) {
     return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
 }
 
+#ifdef SDAG_STAMPS
+// Diagnostic build only: per-phase cycle sums of wave 0 of block 0, read back with sdag_debug_stamps().
+#define STAMP(i)                                                            \
+    do {                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        unsigned long long _t;                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); \
+        st_acc[i] += _t - st_prev;                                          \
+        st_prev = _t;                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// Three-input maximum as ONE instruction.  Written in asm because fmaxf() on accumulator outputs makes the compiler
+// add a canonicalising v_max per operand.  The first argument must already have been touched by compiler-visible
+// code after the MFMAs that produced the others, so the MFMA -> VALU wait states have been inserted.
+__device__ __forceinline__ float max3(float acc, float a, float b) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(acc), "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float max3_abs(float acc, float a, float b) {
+    float r;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(acc), "v"(a), "v"(b));
+    return r;
+}
+
+// Combine a value with the one held by the lane 32 away.  v_permlane32_swap_b32 a, b trades lanes 32-63 of a with
+// lanes 0-31 of b; started from two copies of x it leaves a = (x.lo | x.lo) and b = (x.hi | x.hi), so op(a, b) is
+// the combination in every lane, with no LDS round trip.  (Inline asm with its own wait states: the compiler
+// builtin of the same name folds both results into one register on ROCm 7.2.)
+__device__ __forceinline__ float half_max(float x) {
+    float a = x, b = x;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float half_sum(float x) {
+    float a = x, b = x;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
 
 __device__ void vsum_block(const AttnParams& p, int vb, unsigned char* smem) {
     // vb -> (b, kvh, chunk); 256 threads: 32 column quads x 8 row lanes.
@@ -158,12 +206,30 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     const unsigned short* vbase = p.v + b * p.v_sb + kvh * p.v_sh + st_ch * 8;
     u32x4 kreg[4], vreg[4];
 
-    auto stage_load = [&](int kt) {
+    // Byte offsets of this thread's four rows inside a tile; a tile's base address is wave-uniform, so the loads
+    // need no per-lane 64-bit arithmetic.  Only the last tile of a sequence can run past L and clamps its rows.
+    unsigned koff[4], voff[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int kr = min(kt * KT + st_row + 16 * i, p.L - 1);
-            kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)kr * p.k_sl);
-            vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)kr * p.v_sl);
+    for (int i = 0; i < 4; ++i) {
+        koff[i] = (unsigned)((st_row + 16 * i) * p.k_sl * 2);
+        voff[i] = (unsigned)((st_row + 16 * i) * p.v_sl * 2);
+    }
+    auto stage_load = [&](int kt) {
+        const char* kt_base = reinterpret_cast<const char*>(kbase + (int64_t)kt * KT * p.k_sl);
+        const char* vt_base = reinterpret_cast<const char*>(vbase + (int64_t)kt * KT * p.v_sl);
+        if (kt * KT + KT <= p.L) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                kreg[i] = *reinterpret_cast<const u32x4*>(kt_base + koff[i]);
+                vreg[i] = *reinterpret_cast<const u32x4*>(vt_base + voff[i]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kr = min(kt * KT + st_row + 16 * i, p.L - 1);
+                kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)kr * p.k_sl);
+                vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)kr * p.v_sl);
+            }
         }
     };
     // V goes to LDS as fp16: P V then runs on the f16 MFMA with 11-bit probabilities instead of 8-bit ones.
@@ -181,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
             for (int j = 0; j < 4; ++j) {
                 const unsigned w = vreg[i][j];
                 const float f0 = __uint_as_float(w << 16), f1 = __uint_as_float(w & 0xffff0000u);
-                vmax = fmaxf(vmax, fmaxf(fabsf(f0), fabsf(f1)));
+                vmax = max3_abs(vmax, f0, f1);
                 hv[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(f0, f1));
             }
             *reinterpret_cast<u32x4*>(vd + i * 16 * 256) = hv;
@@ -247,6 +313,10 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     stage_store(0, 1u);
     __syncthreads();
 
+#ifdef SDAG_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
     int cur = 0;
     for (int it = it_begin; it < it_end; ++it) {
         const bool has_next = it + 1 < it_end;
@@ -263,7 +333,51 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         const unsigned char* kb_lds = smem + cur * TILE_BYTES;
         const unsigned char* vb_lds = smem + (2 + cur) * TILE_BYTES;
 
-        // ---- V tile beyond the fp16 range? (rare; workgroup-uniform)
+        STAMP(0);
+        // ---- S^T = K Q^T : two 32-key blocks.  The LDS reads run two k-steps ahead of the MFMAs that consume them.
+        // The mask enters as the initial accumulator: 0 where the pair is allowed, -inf where it is not (a finite
+        // product added to -inf stays -inf).  Accumulator register i of block kb is key 32 kb + (i & 3) + 8 (i >> 2)
+        // + 4 h.  These VALU operations overlap the LDS reads and MFMAs below instead of following them.
+        f32x16 s0, s1;
+        if (mi_cur >= 0) {
+            const unsigned nlo = ~((unsigned)mrow_cur >> (4 * h));
+            const unsigned nhi = ~((unsigned)(mrow_cur >> 32) >> (4 * h));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int bit = (i & 3) + 8 * (i >> 2);
+                s0[i] = __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)nlo, bit, 1) & 0xff800000u);
+                s1[i] = __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)nhi, bit, 1) & 0xff800000u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+        }
+        {
+            bf16x8 ka[8], kb2[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int ch = ((2 * ks + h) ^ kf) << 4;
+                ka[ks] = *reinterpret_cast<const bf16x8*>(kb_lds + k_row_off + ch);
+                kb2[ks] = *reinterpret_cast<const bf16x8*>(kb_lds + 32 * 256 + k_row_off + ch);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[ks], qf[ks], s1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);  // 6 ds_read
+#pragma unroll
+            for (int g = 0; g < 5; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 ds_read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        }
+
+        STAMP(1);
+        STAMP(2);
+        // ---- V tile beyond the fp16 range? (rare; workgroup-uniform).  Checked here so that the LDS read of the
+        // tag is covered by the QK^T MFMAs.
         int ve = 0;
         {
             const unsigned tg = vtag[cur];
@@ -273,45 +387,25 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
             restage_v_scaled(cur, kt_cur, ve);
             __syncthreads();
         }
-
-        // ---- S^T = K Q^T : two 32-key blocks
-        f32x16 s0, s1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int ch = ((2 * ks + h) ^ kf) << 4;
-            const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kb_lds + k_row_off + ch);
-            const bf16x8 kb2 = *reinterpret_cast<const bf16x8*>(kb_lds + 32 * 256 + k_row_off + ch);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2, qf[ks], s1, 0, 0, 0);
-        }
-
-        // ---- mask: accumulator register i of block kb is key 32 kb + (i & 3) + 8 (i >> 2) + 4 h
-        if (mi_cur >= 0) {
-            const unsigned lo = (unsigned)mrow_cur >> (4 * h);
-            const unsigned hi = (unsigned)(mrow_cur >> 32) >> (4 * h);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int bit = (i & 3) + 8 * (i >> 2);
-                s0[i] = ((lo >> bit) & 1u) ? s0[i] : -INFINITY;
-                s1[i] = ((hi >> bit) & 1u) ? s1[i] : -INFINITY;
-            }
-        }
-
         // ---- online softmax (per query = per lane, halves combined by one exchange)
         float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[i], s1[i]));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        for (int i = 1; i < 16; ++i) mx = max3(mx, s0[i], s1[i]);
+        mx = half_max(mx);
         const float m_new = fmaxf(m_run, mx);
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = fast_exp2((m_run - m_safe) * c);
         const float nb = (float)ve - m_safe * c;  // probabilities carry 2^ve when V was scaled by 2^-ve
+        {
+            const f32x2 c2 = {c, c}, nb2 = {nb, nb};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            s0[i] = fast_exp2(__builtin_fmaf(s0[i], c, nb));
-            s1[i] = fast_exp2(__builtin_fmaf(s1[i], c, nb));
+            for (int i = 0; i < 16; i += 2) {
+                f32x2 a = {s0[i], s0[i + 1]}, b2 = {s1[i], s1[i + 1]};
+                a = __builtin_elementwise_fma(a, c2, nb2);    // v_pk_fma_f32: two scaled scores per instruction
+                b2 = __builtin_elementwise_fma(b2, c2, nb2);
+                s0[i] = fast_exp2(a[0]); s0[i + 1] = fast_exp2(a[1]);
+                s1[i] = fast_exp2(b2[0]); s1[i + 1] = fast_exp2(b2[1]);
+            }
         }
 
         // ---- P^T fragments in fp16: registers 8 s .. 8 s + 7 of block kb are k-step (kb, s) of the B operand.
@@ -338,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
             rs1 = __builtin_amdgcn_fdot2(t, ones, rs1, false);
         }
         float rs = rs0 + rs1;
-        rs += __shfl_xor(rs, 32);
+        rs = half_sum(rs);
         if (ve > 0) rs *= __uint_as_float((unsigned)(127 - ve) << 23);
         l_run = l_run * alpha + rs;
         m_run = m_new;
@@ -349,28 +443,48 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
                 for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
         }
 
-        // ---- O^T += V^T P^T
+        STAMP(3);
+        // ---- O^T += V^T P^T.  The transposed reads of one 32-column block of V run ahead of the four MFMAs of the
+        // previous block.
+        {
+            s16x4 va[4][4][2];
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
+            for (int db = 0; db < 4; ++db)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int rbase = (32 * kb + 16 * s) * 256;
-                    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(vb_lds + rbase + v_off[db][0]));
-                    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(vb_lds + rbase + 8 * 256 + v_off[db][1]));
-                    union { s16x4 hlf[2]; f16x8 full; } va;
-                    va.hlf[0] = a0;
-                    va.hlf[1] = a1;
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va.full, pf[kb][s], oacc[db], 0, 0, 0);
-                }
+                    for (int s = 0; s < 2; ++s) {
+                        const int rbase = (32 * kb + 16 * s) * 256;
+                        va[db][2 * kb + s][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(vb_lds + rbase + v_off[db][0]));
+                        va[db][2 * kb + s][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(vb_lds + rbase + 8 * 256 + v_off[db][1]));
+                    }
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        union { s16x4 hlf[2]; f16x8 full; } u;
+                        u.hlf[0] = va[db][2 * kb + s][0];
+                        u.hlf[1] = va[db][2 * kb + s][1];
+                        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(u.full, pf[kb][s], oacc[db], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 1);  // reads of block 0 and half of block 1
+#pragma unroll
+            for (int g = 0; g < 10; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
             }
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 1);
         }
 
+        STAMP(4);
         if (has_next) stage_store(cur ^ 1, seq + 1u);
+        STAMP(5);
         __syncthreads();
+        STAMP(6);
         cur ^= 1;
         kt_cur = kt_nxt; mi_cur = mi_nxt; mrow_cur = mrow_nxt;
         // The pair fetched above is consumed only now: keeping it opaque in vector registers until here stops
@@ -380,6 +494,12 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         mi_nxt = __builtin_amdgcn_readfirstlane(mi_nn);
     }
 
+#ifdef SDAG_STAMPS
+    if (blockIdx.x == 0 && tid == 0) {
+        for (int i = 0; i < 7; ++i) g_stamps[i] = st_acc[i];
+        g_stamps[7] = (unsigned long long)(it_end - it_begin);
+    }
+#endif
     if (!head_ok) return;
 
     // ---- epilogue.  O^T register i of block db is column d = 32 db + (i & 3) + 8 (i >> 2) + 4 h of row `row`.
@@ -628,3 +748,11 @@ extern "C" int sdag_mask_materialize(const int32_t* desc_host, const int32_t* de
     SDAG_HIP_CHECK(hipGetLastError());
     return SDAG_OK;
 }
+
+#ifdef SDAG_STAMPS
+extern "C" int sdag_debug_stamps(unsigned long long* out) {
+    SDAG_HIP_CHECK(hipDeviceSynchronize());
+    SDAG_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(sdag::g_stamps), sizeof(unsigned long long) * 16));
+    return SDAG_OK;
+}
+#endif

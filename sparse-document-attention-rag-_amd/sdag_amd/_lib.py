@@ -13,7 +13,7 @@ import subprocess
 import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdag_hip.so")
+LIB_PATH = os.environ.get("SDAG_HIP_LIB") or os.path.join(_HERE, "libsdag_hip.so")  # override: diagnostic builds
 CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 
 SDAG_OK = 0
