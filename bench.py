@@ -6,8 +6,10 @@ One step = one batch of 32 queries through the hot path, inputs resident in HBM:
     (one ``sdag_dense_topk`` call: scan kernel + merge kernel);
   * SDAG: for each of the 32 queries, the masked attention of all 32 layers of a Llama-3-8B-shaped prompt
     (32 query heads, 8 KV heads, head_dim 128, bf16; system prefix 60 tokens, 10 documents x 300 tokens with
-    1-token separators, 30 question tokens -> L = 3100, no neighbours), one ``sdag_attn_fwd`` call per
-    (query, layer) with B = 1, as the reference calls its model once per query.
+    1-token separators, 30 question tokens -> L = 3100, no neighbours).  Default ``--mode batched``: one
+    ``sdag_attn_fwd_batch`` launch per layer over the 32 queries, every query with its own descriptor and its own
+    Q/K/V/O memory; ``--mode per_query``: one ``sdag_attn_fwd`` call per (query, layer) with B = 1, the way the
+    reference calls its model once per query (its cost is also reported under "stage" in batched mode).
 Metric: queries/sec over both stages.  With --gpus N every rank runs its own query batch against a replicated
 corpus (weak scaling, no data-path collective); rank 0 prints ONE JSON line.
 
@@ -116,6 +118,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--corpus-n", type=int, default=CFG["corpus_n"])
+    ap.add_argument("--mode", choices=("batched", "per_query"), default="batched")
     args = ap.parse_args()
     cfg = dict(CFG, corpus_n=args.corpus_n)
 
@@ -141,15 +144,26 @@ def main():
     pairs = desc.allowed_pairs
     nl, Hq, Hkv, D = cfg["n_layers"], cfg["Hq"], cfg["Hkv"], cfg["D"]
 
-    # ---- inputs resident in HBM: distinct Q/K/V per layer (2 GB, far beyond the 256 MiB last-level cache)
-    qs, ks, vs, os_ = [], [], [], []
-    for layer in range(nl):
-        g = torch.Generator(device=dev).manual_seed(1000 * rank + layer)
-        # [B, L, H, D] storage viewed as [B, H, L, D]: the strided views transformers hands to attention
-        qs.append(torch.randn((1, L, Hq, D), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16).transpose(1, 2))
-        ks.append(torch.randn((1, L, Hkv, D), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16).transpose(1, 2))
-        vs.append(torch.randn((1, L, Hkv, D), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16).transpose(1, 2))
-        os_.append(torch.empty((1, L, Hq, D), device=dev, dtype=torch.bfloat16))
+    # ---- inputs resident in HBM.  per_query: distinct Q/K/V/O per layer (2 GB).  batched: 4 rotating sets of
+    # [32 queries, L, H, D] tensors (2 GB each, every query its own memory); both are far beyond the 256 MiB
+    # last-level cache, so every launch streams its operands from HBM.
+    def make_set(nb, seed):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        mk = lambda h: torch.randn((nb, L, h, D), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16).transpose(1, 2)
+        return mk(Hq), mk(Hkv), mk(Hkv), torch.empty((nb, L, Hq, D), device=dev, dtype=torch.bfloat16)
+
+    batched = args.mode == "batched"
+    nb = cfg["batch"]
+    if batched:
+        descs = [sdag_amd.from_spans(L, cfg["sys_len"], spans, qa, None, max_items_per_unit=64) for _ in range(nb)]
+        bdesc = sdag_amd.BatchDescriptor(descs)        # one descriptor per query, as different prompts would have
+        sets = [make_set(nb, 1000 * rank + i) for i in range(4)]
+        bcalls = [sdag_amd.BoundBatchAttention(q_, k_, v_, bdesc, o_) for q_, k_, v_, o_ in sets]
+        layer_calls = [bcalls[i % len(bcalls)] for i in range(nl)]
+        pq_sets = [tuple(t[:1] for t in sets[i]) for i in range(4)]
+    else:
+        pq_sets = [make_set(1, 1000 * rank + i) for i in range(nl)]
+    pq_calls = [sdag_amd.BoundAttention(q_, k_, v_, desc, o_) for q_, k_, v_, o_ in pq_sets]
     corpus = make_corpus(cfg["corpus_n"], cfg["dim"], dev, seed=0)
     index = sdag_amd.FlatIPIndex(cfg["dim"], device=dev)
     index._corpus = corpus  # already resident; add() would copy
@@ -157,7 +171,6 @@ def main():
     Q = torch.randn((cfg["batch"], cfg["dim"]), generator=gq, device=dev, dtype=torch.float32)
     Q = Q / Q.norm(dim=1, keepdim=True)
 
-    calls = [sdag_amd.BoundAttention(qs[i], ks[i], vs[i], desc, os_[i]) for i in range(nl)]
     stream = int(torch.cuda.current_stream(dev).cuda_stream)
     ev = lambda: torch.cuda.Event(enable_timing=True)
     sdag_ms, retr_ms = [], []
@@ -167,9 +180,13 @@ def main():
         e0.record()
         index.search_device(Q, cfg["top_k"])
         e1.record()
-        for _ in range(cfg["batch"]):
-            for call in calls:
+        if batched:
+            for call in layer_calls:
                 call(stream)
+        else:
+            for _ in range(cfg["batch"]):
+                for call in pq_calls:
+                    call(stream)
         e2.record()
         if timed:
             sdag_ms.append((e1, e2))
@@ -194,18 +211,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    n_calls = args.steps * cfg["batch"] * nl
+    n_launches = args.steps * nl * (1 if batched else cfg["batch"])
+    q_per_launch = cfg["batch"] if batched else 1
     t_sdag = sum(a.elapsed_time(b) for a, b in sdag_ms) * 1e-3
     t_retr = sum(a.elapsed_time(b) for a, b in retr_ms) * 1e-3
-    per_call = t_sdag / n_calls
-    bytes_per_call = L * (2 * Hq + 2 * Hkv) * D * 2        # Q + K + V + O of one layer, each read/written once
-    flops_per_call = 4 * D * pairs * Hq                    # QK^T + PV over the allowed pairs
-    achieved = bytes_per_call / per_call
+    per_launch = t_sdag / n_launches
+    bytes_per_launch = q_per_launch * L * (2 * Hq + 2 * Hkv) * D * 2   # Q + K + V + O, each read/written once
+    flops_per_launch = q_per_launch * 4 * D * pairs * Hq               # QK^T + PV over the allowed pairs
+    achieved = bytes_per_launch / per_launch
+    # the per-query call (B = 1, one launch per query and layer), timed outside the throughput region
+    for c in pq_calls[:4]:
+        c(stream)
+    torch.cuda.synchronize()
+    ea, eb = ev(), ev()
+    ea.record()
+    for _ in range(8):
+        for c in pq_calls[:4]:
+            c(stream)
+    eb.record()
+    torch.cuda.synchronize()
+    pq_us = ea.elapsed_time(eb) * 1e3 / 32
     traffic = None
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
         try:
-            traffic = json.load(open(tp)).get("sdag_attn_main_bytes_per_launch")
+            traffic = json.load(open(tp)).get("sdag_attn_main_bytes_per_launch_" + args.mode)
         except Exception:
             traffic = None
     out = {
@@ -223,16 +253,17 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"cfg2+cfg3: dense top-{cfg['top_k']} over {cfg['corpus_n']}x{cfg['dim']} f32 corpus + SDAG "
                                f"attention 32 layers x (Hq32,Hkv8,D128) L={L} (10 docs x 300 tok, no neighbours), "
-                               f"{cfg['batch']} queries/step", "batch_queries": cfg["batch"], "seq_len": L,
+                               f"{cfg['batch']} queries/step, attention launches {args.mode}", "batch_queries": cfg["batch"], "seq_len": L,
                    "parallelism": f"dp{world} over queries, corpus replicated"},
         "stage": {"retrieval_ms_per_batch": t_retr / args.steps * 1e3, "sdag_ms_per_query": t_sdag / (args.steps * cfg["batch"]) * 1e3,
                   "retrieval_qps": args.steps * cfg["batch"] / t_retr, "sdag_qps": args.steps * cfg["batch"] / t_sdag,
                   "retrieval_hbm_frac": (cfg["corpus_n"] * cfg["dim"] * 4 / (t_retr / args.steps)) / HBM_PEAK,
-                  "sdag_mfma_frac": flops_per_call / per_call / BF16_PEAK},
-        "roofline": {"kernel": "sdag_attn_fwd (sdag_attn_main + sdag_attn_combine, one call = one layer of one query)",
+                  "sdag_mfma_frac": flops_per_launch / per_launch / BF16_PEAK,
+                  "sdag_per_query_call_us": pq_us, "sdag_per_query_call_qps": 1e6 / (pq_us * nl)},
+        "roofline": {"kernel": "sdag_attn_main + sdag_attn_combine, one launch = one layer of %d quer%s" % (q_per_launch, "ies" if q_per_launch > 1 else "y"),
                      "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK, "traffic": traffic, "us_per_launch": per_call * 1e6,
-                     "algorithmic_bytes_per_launch": bytes_per_call, "flops_per_launch": flops_per_call},
+                     "frac": achieved / HBM_PEAK, "traffic": traffic, "us_per_launch": per_launch * 1e6,
+                     "algorithmic_bytes_per_launch": bytes_per_launch, "flops_per_launch": flops_per_launch},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -100,6 +100,28 @@ int sdag_attn_fwd(const void* q, const void* k, const void* v, void* o,
                   const int32_t* desc_host, const int32_t* desc_dev,
                   void* workspace, int64_t workspace_bytes, int out_dtype, void* stream);
 
+/* Several sequences in one launch, each with its OWN descriptor (different prompts have different spans and
+ * lengths).  The reference runs one query at a time (src/pipeline/main.py:469-496 calls
+ * run_rag_with_doc_isolation per query); batching the masked prefill of many queries is how this build fills
+ * the GPU, so these entry points have no single call site to cite beyond SDAG.py:176.
+ *
+ * sdag_batch_build concatenates B host descriptors (the same pointer may repeat) with a table of
+ * (sequence, unit) pairs in sequence-major order.  Tensors are padded to Lmax rows per sequence:
+ * q [B, Hq, Lmax, D], k / v [B, Hkv, Lmax, D], o [B, Lmax, Hq, D] through the usual strides; rows at and
+ * beyond a sequence's own length are neither read as queries nor written. */
+int sdag_batch_build(const int32_t* const* descs_host, int B, int32_t* out, int64_t cap_words, int64_t* n_words);
+
+int64_t sdag_attn_batch_workspace_bytes(const int32_t* batch_host, int Hq, int Hkv);
+
+int sdag_attn_fwd_batch(const void* q, const void* k, const void* v, void* o,
+                        int64_t q_sb, int64_t q_sh, int64_t q_sl,
+                        int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                        int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                        int64_t o_sb, int64_t o_sl, int64_t o_sh,
+                        int B, int Hq, int Hkv, int Lmax, int D, float scale,
+                        const int32_t* batch_host, const int32_t* batch_dev,
+                        void* workspace, int64_t workspace_bytes, int out_dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Exact inner-product search.  Replaces  scores, indices = index.search(q, top_k)
  * (src/pipeline/retrieval/dense.py:82-84; the arithmetic of the reference is inside faiss).

@@ -57,16 +57,20 @@ struct AttnParams {
     int64_t k_sb, k_sh, k_sl;
     int64_t v_sb, v_sh, v_sl;
     int64_t o_sb, o_sl, o_sh;
-    int B, Hq, Hkv, L;
+    int B, Hq, Hkv;
     int G;        // query heads per kv head
     int HG;       // groups of 4 query heads per kv head
     int n_units;
     int n_main_blocks;
     int out_f32;
     float c;      // scale * log2(e)
-    const int32_t* desc;
-    float* part_o;   // [slot][B][Hq][32][128]
-    float* part_ml;  // [slot][B][Hq][32][2]
+    const int32_t* desc;  // single descriptor shared by every batch element (btab == nullptr)
+    const int32_t* btab;  // batch table + per-sequence descriptors (see common.h), or nullptr
+    int n_slots;          // partial-result slots of the shared descriptor
+    int L;                // length of the shared descriptor
+    int off_units, off_items, off_masks;  // word offsets inside the shared descriptor / of the pair records in btab
+    float* part_o;   // [global slot][Hq][32][128]
+    float* part_ml;  // [global slot][Hq][32][2]
     float* vsum;     // [B][Hkv][VSUM_CHUNKS][128]
 };
 
@@ -128,8 +132,11 @@ __device__ void vsum_block(const AttnParams& p, int vb, unsigned char* smem) {
     const int chunk = vb % VSUM_CHUNKS;
     const int kvh = (vb / VSUM_CHUNKS) % p.Hkv;
     const int b = vb / (VSUM_CHUNKS * p.Hkv);
-    const int rows_per = (p.L + VSUM_CHUNKS - 1) / VSUM_CHUNKS;
-    const int r0 = chunk * rows_per, r1 = min(p.L, r0 + rows_per);
+    const int32_t* desc = p.btab ? p.btab + p.btab[p.btab[BT_OFF_DESC] + b] : p.desc;
+    if (desc[H_NUNIFORM] == 0) return;  // this sequence has no row that needs mean(V)
+    const int L = desc[H_L];
+    const int rows_per = (L + VSUM_CHUNKS - 1) / VSUM_CHUNKS;
+    const int r0 = chunk * rows_per, r1 = min(L, r0 + rows_per);
     const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const unsigned short* base = p.v + b * p.v_sb + kvh * p.v_sh + cq * 4;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -169,27 +176,41 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     const int n_hslots = p.Hkv * p.HG;
     const int hslot = bid % n_hslots;
     const int rest = bid / n_hslots;
-    const int unit = rest % p.n_units;
-    const int b = rest / p.n_units;
+    // ---- the work record: everything needed to start loading comes from ONE 32/64-byte read whose address
+    // depends only on kernel arguments (no chain of dependent header reads).
+    int b, rb, it_begin, it_end, gslot, L, kt_first, mi_first;
+    unsigned uniform_bits;
+    const int32_t* __restrict__ items;
+    const uint64_t* __restrict__ masks;
+    if (p.btab) {  // batch of sequences, each with its own descriptor
+        const int32_t* __restrict__ rec = p.btab + p.off_units + (int64_t)rest * PAIR_WORDS;
+        b = rec[0]; rb = rec[1]; it_begin = rec[2]; it_end = rec[3]; gslot = rec[4];
+        uniform_bits = (unsigned)rec[5]; L = rec[6]; kt_first = rec[7]; mi_first = rec[8];
+        items = p.btab + rec[9];
+        masks = reinterpret_cast<const uint64_t*>(p.btab + rec[10]);
+    } else {
+        const int unit = rest % p.n_units;
+        b = rest / p.n_units;
+        const int32_t* __restrict__ rec = p.desc + p.off_units + unit * UNIT_WORDS;
+        rb = rec[0]; it_begin = rec[1]; it_end = rec[2];
+        gslot = rec[3] < 0 ? -1 : b * p.n_slots + rec[3];
+        uniform_bits = (unsigned)rec[4]; kt_first = rec[5]; mi_first = rec[6];
+        L = p.L;
+        items = p.desc + p.off_items;
+        masks = reinterpret_cast<const uint64_t*>(p.desc + p.off_masks);
+    }
     const int kvh = hslot % p.Hkv;
     const int hg = hslot / p.Hkv;
     const int hin = hg * 4 + wave;
     const bool head_ok = hin < p.G;
     const int hq = kvh * p.G + (head_ok ? hin : p.G - 1);
-
-    const int32_t* __restrict__ desc = p.desc;
-    const int32_t* up = desc + desc[H_OFF_UNITS] + unit * 4;
-    const int rb = up[0], it_begin = up[1], it_end = up[2], slot = up[3];
-    const int32_t* __restrict__ items = desc + desc[H_OFF_ITEMS];
-    const uint64_t* __restrict__ masks = reinterpret_cast<const uint64_t*>(desc + desc[H_OFF_MASKS]);
-    const unsigned uniform_bits = (unsigned)desc[desc[H_OFF_RBINFO] + rb * 2];
     unsigned* vtag = reinterpret_cast<unsigned*>(smem + 4 * TILE_BYTES);
     if (tid < 2) vtag[tid] = 0;
 
     const int r = lane & 31;  // query row inside the block (S^T / O^T column)
     const int h = lane >> 5;
     const int row = rb * RB + r;
-    const int row_ld = min(row, p.L - 1);
+    const int row_ld = min(row, L - 1);
 
     // ---- Q fragments: B operand of S^T = K Q^T; lane (r, h) holds Q[row][16 ks + 8 h .. +7].
     bf16x8 qf[8];
@@ -217,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     auto stage_load = [&](int kt) {
         const char* kt_base = reinterpret_cast<const char*>(kbase + (int64_t)kt * KT * p.k_sl);
         const char* vt_base = reinterpret_cast<const char*>(vbase + (int64_t)kt * KT * p.v_sl);
-        if (kt * KT + KT <= p.L) {
+        if (kt * KT + KT <= L) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 kreg[i] = *reinterpret_cast<const u32x4*>(kt_base + koff[i]);
@@ -226,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int kr = min(kt * KT + st_row + 16 * i, p.L - 1);
+                const int kr = min(kt * KT + st_row + 16 * i, L - 1);
                 kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)kr * p.k_sl);
                 vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)kr * p.v_sl);
             }
@@ -263,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         unsigned char* vd = smem + (2 + buf) * TILE_BYTES + st_off;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int kr = min(kt * KT + st_row + 16 * i, p.L - 1);
+            const int kr = min(kt * KT + st_row + 16 * i, L - 1);
             const u32x4 raw = *reinterpret_cast<const u32x4*>(vbase + (int64_t)kr * p.v_sl);
             u32x4 hv;
 #pragma unroll
@@ -301,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     // ---- software pipeline over the unit's items: the (tile, mask) pair of the NEXT tile is known one
     // iteration ahead, so its K/V rows and mask words are requested before the current tile is computed, and
     // the pair after that is fetched meanwhile.
-    int kt_cur = items[it_begin * 2], mi_cur = items[it_begin * 2 + 1];
+    int kt_cur = kt_first, mi_cur = mi_first;
     int kt_nxt = 0, mi_nxt = -1;
     if (it_begin + 1 < it_end) {
         kt_nxt = items[(it_begin + 1) * 2];
@@ -503,8 +524,8 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     if (!head_ok) return;
 
     // ---- epilogue.  O^T register i of block db is column d = 32 db + (i & 3) + 8 (i >> 2) + 4 h of row `row`.
-    if (slot >= 0) {
-        const int64_t prow = (((int64_t)slot * p.B + b) * p.Hq + hq) * RB + r;
+    if (gslot >= 0) {
+        const int64_t prow = ((int64_t)gslot * p.Hq + hq) * RB + r;
         float* po = p.part_o + prow * D;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
@@ -519,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         }
         return;
     }
-    if (row >= p.L || ((uniform_bits >> r) & 1u) || !(l_run > 0.f)) return;
+    if (row >= L || ((uniform_bits >> r) & 1u) || !(l_run > 0.f)) return;
     const float inv = 1.0f / l_run;
     const int64_t obase = b * p.o_sb + (int64_t)row * p.o_sl + hq * p.o_sh;
     if (p.out_f32) {
@@ -549,31 +570,43 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
 // grid: (n_split * B * Hq) blocks of 256 threads for the merge, then ceil(n_uniform * B * Hq / 8) blocks for
 // the uniform rows (8 (row, head) pairs per block, 32 threads x 4 columns each).
 __global__ __launch_bounds__(256) void sdag_attn_combine(const AttnParams p, int n_merge_blocks) {
-    const int32_t* desc = p.desc;
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < n_merge_blocks) {
         const int hq = blockIdx.x % p.Hq;
         const int rest = blockIdx.x / p.Hq;
-        const int b = rest % p.B;
-        const int e = rest / p.B;
+        int b, e, slot_base;
+        const int32_t* desc;
+        if (p.btab) {
+            const int32_t* bt = p.btab;
+            const int32_t* mr = bt + bt[BT_OFF_MERGE] + 2 * rest;
+            b = mr[0];
+            e = mr[1];
+            desc = bt + bt[bt[BT_OFF_DESC] + b];
+            slot_base = bt[bt[BT_OFF_SLOTBASE] + b];
+        } else {
+            b = rest % p.B;
+            e = rest / p.B;
+            desc = p.desc;
+            slot_base = b * p.n_slots;
+        }
         const int32_t* sp = desc + desc[H_OFF_SPLIT] + e * 4;
-        const int rb = sp[0], first = sp[1], n = sp[2];
+        const int rb = sp[0], first = slot_base + sp[1], n = sp[2];
         // thread -> row (tid >> 3), 16 columns starting at (tid & 7) * 16
         const int r = tid >> 3, c0 = (tid & 7) * 16;
         const int row = rb * RB + r;
-        if (row >= p.L) return;
+        if (row >= desc[H_L]) return;
         float mmax = -INFINITY;
         for (int s = 0; s < n; ++s) {
-            const int64_t prow = (((int64_t)(first + s) * p.B + b) * p.Hq + hq) * RB + r;
+            const int64_t prow = ((int64_t)(first + s) * p.Hq + hq) * RB + r;
             mmax = fmaxf(mmax, p.part_ml[prow * 2]);
         }
-        if (mmax == -INFINITY) return;  // uniform row: handled below
+        if (mmax == -INFINITY) return;  // a row that allows nothing: handled below
         float acc[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         float den = 0.f;
         for (int s = 0; s < n; ++s) {
-            const int64_t prow = (((int64_t)(first + s) * p.B + b) * p.Hq + hq) * RB + r;
+            const int64_t prow = ((int64_t)(first + s) * p.Hq + hq) * RB + r;
             const float ms = p.part_ml[prow * 2];
             const float w = fast_exp2((ms - mmax) * p.c);  // ms = -inf -> 0
             den += w * p.part_ml[prow * 2 + 1];
@@ -608,16 +641,25 @@ __global__ __launch_bounds__(256) void sdag_attn_combine(const AttnParams p, int
         }
         return;
     }
-    // ---- uniform rows: softmax over all-equal scores = 1/L on every key -> mean of V over all L keys
-    const int n_uni = desc[H_NUNIFORM];
+    // ---- rows that allow nothing: softmax over all-equal scores = 1/L on every key -> mean of V over all L keys
     const int64_t pair = (int64_t)(blockIdx.x - n_merge_blocks) * 8 + (tid >> 5);
-    const int64_t n_pairs = (int64_t)n_uni * p.B * p.Hq;
-    if (pair >= n_pairs) return;
+    int b, row, L;
     const int hq = pair % p.Hq;
     const int64_t rest = pair / p.Hq;
-    const int b = rest % p.B;
-    const int ui = rest / p.B;
-    const int row = desc[desc[H_OFF_UNIFORM] + ui];
+    if (p.btab) {
+        const int32_t* bt = p.btab;
+        if (rest >= bt[BT_NUNIFORM]) return;
+        const int32_t* ur = bt + bt[BT_OFF_UNIFORM] + 2 * rest;
+        b = ur[0];
+        row = ur[1];
+        L = bt[bt[bt[BT_OFF_DESC] + b] + H_L];
+    } else {
+        const int32_t* desc = p.desc;
+        if (rest >= (int64_t)desc[H_NUNIFORM] * p.B) return;
+        b = rest % p.B;
+        row = desc[desc[H_OFF_UNIFORM] + rest / p.B];
+        L = desc[H_L];
+    }
     const int kvh = hq / p.G;
     const int c0 = (tid & 31) * 4;
     const float* vs = p.vsum + (int64_t)(b * p.Hkv + kvh) * VSUM_CHUNKS * 128 + c0;
@@ -626,7 +668,7 @@ __global__ __launch_bounds__(256) void sdag_attn_combine(const AttnParams p, int
         const f32x4 x = *reinterpret_cast<const f32x4*>(vs + ch * 128);
         t += x;
     }
-    const float invL = 1.0f / (float)p.L;
+    const float invL = 1.0f / (float)L;
     const int64_t obase = b * p.o_sb + (int64_t)row * p.o_sl + hq * p.o_sh + c0;
     if (p.out_f32) {
         f32x4 w = {t[0] * invL, t[1] * invL, t[2] * invL, t[3] * invL};
@@ -650,8 +692,8 @@ __global__ __launch_bounds__(256) void sdag_mask_expand(const int32_t* desc, uns
     const int32_t* items = desc + desc[H_OFF_ITEMS];
     const uint64_t* masks = reinterpret_cast<const uint64_t*>(desc + desc[H_OFF_MASKS]);
     for (int u = 0; u < n_units; ++u) {
-        if (units[u * 4] != rb) continue;
-        for (int it = units[u * 4 + 1]; it < units[u * 4 + 2]; ++it) {
+        if (units[u * UNIT_WORDS] != rb) continue;
+        for (int it = units[u * UNIT_WORDS + 1]; it < units[u * UNIT_WORDS + 2]; ++it) {
             const int kt = items[it * 2], mi = items[it * 2 + 1];
             for (int e = tid; e < RB * KT; e += 256) {
                 const int r = e >> 6, cidx = e & 63;
@@ -669,13 +711,75 @@ __global__ __launch_bounds__(256) void sdag_mask_expand(const int32_t* desc, uns
 
 using namespace sdag;
 
+namespace {
+
+int64_t workspace_bytes(int64_t n_slots_total, int64_t n_uniform_total, int B, int Hq, int Hkv) {
+    int64_t bytes = n_slots_total * Hq * RB * (D + 2) * (int64_t)sizeof(float);
+    if (n_uniform_total > 0) bytes += (int64_t)B * Hkv * VSUM_CHUNKS * 128 * sizeof(float);
+    return (bytes + 255) & ~255ll;
+}
+
+struct Tensors {
+    const void *q, *k, *v;
+    void* o;
+    int64_t q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sl, o_sh;
+};
+
+int check_common(const Tensors& t, int B, int Hq, int Hkv, int L, int Dh, float scale, int out_dtype) {
+    if (Dh != D) return fail(SDAG_ERR_ARG, "head_dim %d not supported (only 128)", Dh);
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || L <= 0 || Hq % Hkv) return fail(SDAG_ERR_ARG, "bad B/Hq/Hkv/L");
+    if (!(scale > 0.f)) return fail(SDAG_ERR_ARG, "scale must be positive");
+    if (out_dtype != SDAG_OUT_BF16 && out_dtype != SDAG_OUT_F32) return fail(SDAG_ERR_ARG, "bad out_dtype");
+    if (!t.q || !t.k || !t.v || !t.o) return fail(SDAG_ERR_ARG, "NULL tensor pointer");
+    const int64_t strides[] = {t.q_sb, t.q_sh, t.q_sl, t.k_sb, t.k_sh, t.k_sl, t.v_sb, t.v_sh, t.v_sl, t.o_sb, t.o_sl, t.o_sh};
+    for (int64_t st : strides)
+        if (st < 0 || (st & 7)) return fail(SDAG_ERR_ARG, "strides must be non-negative multiples of 8 elements");
+    if ((int64_t)L * t.k_sl * 2 >= (1ll << 32) || (int64_t)L * t.v_sl * 2 >= (1ll << 32))
+        return fail(SDAG_ERR_ARG, "one (batch, head) slice of K or V must span less than 4 GiB");
+    if (((uintptr_t)t.q | (uintptr_t)t.k | (uintptr_t)t.v | (uintptr_t)t.o) & 15) return fail(SDAG_ERR_ARG, "tensor pointers must be 16-byte aligned");
+    return SDAG_OK;
+}
+
+// Launch main (+ column-sum blocks) and, if anything needs it, the combine kernel.
+int launch(AttnParams& p, const Tensors& t, int B, int Hq, int Hkv, float scale, int out_dtype, int64_t n_pairs,
+           int64_t n_slots_total, int64_t n_merge_entries, int64_t n_uniform_total, void* workspace, hipStream_t st) {
+    p.q = (const unsigned short*)t.q; p.k = (const unsigned short*)t.k; p.v = (const unsigned short*)t.v; p.o = t.o;
+    p.q_sb = t.q_sb; p.q_sh = t.q_sh; p.q_sl = t.q_sl;
+    p.k_sb = t.k_sb; p.k_sh = t.k_sh; p.k_sl = t.k_sl;
+    p.v_sb = t.v_sb; p.v_sh = t.v_sh; p.v_sl = t.v_sl;
+    p.o_sb = t.o_sb; p.o_sl = t.o_sl; p.o_sh = t.o_sh;
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv;
+    p.G = Hq / Hkv;
+    p.HG = (p.G + 3) / 4;
+    p.out_f32 = out_dtype == SDAG_OUT_F32;
+    p.c = scale * 1.4426950408889634f;
+    float* ws = (float*)workspace;
+    p.part_o = ws;
+    p.part_ml = ws + n_slots_total * Hq * RB * D;
+    p.vsum = p.part_ml + n_slots_total * Hq * RB * 2;
+    const int64_t main_blocks = n_pairs * Hkv * p.HG;
+    const int64_t vsum_blocks = n_uniform_total > 0 ? (int64_t)B * Hkv * VSUM_CHUNKS : 0;
+    if (main_blocks + vsum_blocks > 0x7fffffff) return fail(SDAG_ERR_ARG, "grid too large");
+    p.n_main_blocks = (int)main_blocks;
+    if (main_blocks + vsum_blocks > 0) {
+        hipLaunchKernelGGL(sdag_attn_main, dim3((unsigned)(main_blocks + vsum_blocks)), dim3(256), 0, st, p);
+        SDAG_HIP_CHECK(hipGetLastError());
+    }
+    const int64_t n_merge = n_merge_entries * Hq;
+    const int64_t cblocks = n_merge + (n_uniform_total * Hq + 7) / 8;
+    if (cblocks > 0x7fffffff) return fail(SDAG_ERR_ARG, "grid too large");
+    if (cblocks > 0) {
+        hipLaunchKernelGGL(sdag_attn_combine, dim3((unsigned)cblocks), dim3(256), 0, st, p, (int)n_merge);
+        SDAG_HIP_CHECK(hipGetLastError());
+    }
+    return SDAG_OK;
+}
+
+}  // namespace
+
 extern "C" int64_t sdag_attn_workspace_bytes(const int32_t* d, int B, int Hq, int Hkv) {
     if (!desc_ok(d) || B <= 0 || Hq <= 0 || Hkv <= 0) return -1;
-    int64_t bytes = 0;
-    const int64_t n_slots = d[H_NSLOTS];
-    bytes += n_slots * B * Hq * RB * (D + 2) * (int64_t)sizeof(float);
-    if (d[H_NUNIFORM] > 0) bytes += (int64_t)B * Hkv * VSUM_CHUNKS * 128 * sizeof(float);
-    return (bytes + 255) & ~255ll;
+    return workspace_bytes((int64_t)d[H_NSLOTS] * B, (int64_t)d[H_NUNIFORM] * B, B, Hq, Hkv);
 }
 
 extern "C" int sdag_attn_fwd(const void* q, const void* k, const void* v, void* o,
@@ -685,58 +789,58 @@ extern "C" int sdag_attn_fwd(const void* q, const void* k, const void* v, void* 
                              int64_t o_sb, int64_t o_sl, int64_t o_sh,
                              int B, int Hq, int Hkv, int L, int Dh, float scale,
                              const int32_t* desc_host, const int32_t* desc_dev,
-                             void* workspace, int64_t workspace_bytes, int out_dtype, void* stream) {
-    if (Dh != D) return fail(SDAG_ERR_ARG, "head_dim %d not supported (only 128)", Dh);
+                             void* workspace, int64_t workspace_bytes_, int out_dtype, void* stream) {
+    const Tensors t = {q, k, v, o, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sl, o_sh};
+    if (int rc = check_common(t, B, Hq, Hkv, L, Dh, scale, out_dtype)) return rc;
     if (!desc_ok(desc_host)) return fail(SDAG_ERR_DESC, "desc_host is not a descriptor");
     if (!desc_dev) return fail(SDAG_ERR_ARG, "desc_dev is NULL");
     if (desc_host[H_L] != L) return fail(SDAG_ERR_DESC, "descriptor is for L=%d, call has L=%d", desc_host[H_L], L);
-    if (B <= 0 || Hq <= 0 || Hkv <= 0 || L <= 0 || Hq % Hkv) return fail(SDAG_ERR_ARG, "bad B/Hq/Hkv/L");
-    if (!(scale > 0.f)) return fail(SDAG_ERR_ARG, "scale must be positive");
-    if (out_dtype != SDAG_OUT_BF16 && out_dtype != SDAG_OUT_F32) return fail(SDAG_ERR_ARG, "bad out_dtype");
-    if (!q || !k || !v || !o) return fail(SDAG_ERR_ARG, "NULL tensor pointer");
-    const int64_t strides[] = {q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sl, o_sh};
-    for (int64_t s : strides)
-        if (s < 0 || (s & 7)) return fail(SDAG_ERR_ARG, "strides must be non-negative multiples of 8 elements");
-    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return fail(SDAG_ERR_ARG, "tensor pointers must be 16-byte aligned");
     const int64_t need = sdag_attn_workspace_bytes(desc_host, B, Hq, Hkv);
-    if (need > 0 && (!workspace || workspace_bytes < need)) return fail(SDAG_ERR_CAPACITY, "workspace needs %lld bytes", (long long)need);
-
+    if (need > 0 && (!workspace || workspace_bytes_ < need)) return fail(SDAG_ERR_CAPACITY, "workspace needs %lld bytes", (long long)need);
     AttnParams p;
-    p.q = (const unsigned short*)q; p.k = (const unsigned short*)k; p.v = (const unsigned short*)v; p.o = o;
-    p.q_sb = q_sb; p.q_sh = q_sh; p.q_sl = q_sl;
-    p.k_sb = k_sb; p.k_sh = k_sh; p.k_sl = k_sl;
-    p.v_sb = v_sb; p.v_sh = v_sh; p.v_sl = v_sl;
-    p.o_sb = o_sb; p.o_sl = o_sl; p.o_sh = o_sh;
-    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.L = L;
-    p.G = Hq / Hkv;
-    p.HG = (p.G + 3) / 4;
-    p.n_units = desc_host[H_NUNITS];
-    p.out_f32 = out_dtype == SDAG_OUT_F32;
-    p.c = scale * 1.4426950408889634f;
     p.desc = desc_dev;
-    const int64_t n_slots = desc_host[H_NSLOTS];
-    float* ws = (float*)workspace;
-    p.part_o = ws;
-    p.part_ml = ws + n_slots * B * Hq * RB * D;
-    p.vsum = p.part_ml + n_slots * B * Hq * RB * 2;
-    const int n_uni = desc_host[H_NUNIFORM];
-    const int64_t main_blocks = (int64_t)p.n_units * Hkv * p.HG * B;
-    const int64_t vsum_blocks = n_uni > 0 ? (int64_t)B * Hkv * VSUM_CHUNKS : 0;
-    if (main_blocks + vsum_blocks > 0x7fffffff) return fail(SDAG_ERR_ARG, "grid too large");
-    p.n_main_blocks = (int)main_blocks;
-    hipStream_t st = (hipStream_t)stream;
-    if (main_blocks + vsum_blocks > 0) {
-        hipLaunchKernelGGL(sdag_attn_main, dim3((unsigned)(main_blocks + vsum_blocks)), dim3(256), 0, st, p);
-        SDAG_HIP_CHECK(hipGetLastError());
-    }
-    const int n_merge = desc_host[H_NSPLIT] * B * Hq;
-    const int64_t n_pairs = (int64_t)n_uni * B * Hq;
-    const int64_t cblocks = n_merge + (n_pairs + 7) / 8;
-    if (cblocks > 0) {
-        hipLaunchKernelGGL(sdag_attn_combine, dim3((unsigned)cblocks), dim3(256), 0, st, p, n_merge);
-        SDAG_HIP_CHECK(hipGetLastError());
-    }
-    return SDAG_OK;
+    p.btab = nullptr;
+    p.n_units = desc_host[H_NUNITS];
+    p.n_slots = desc_host[H_NSLOTS];
+    p.L = L;
+    p.off_units = desc_host[H_OFF_UNITS];
+    p.off_items = desc_host[H_OFF_ITEMS];
+    p.off_masks = desc_host[H_OFF_MASKS];
+    return launch(p, t, B, Hq, Hkv, scale, out_dtype, (int64_t)p.n_units * B, (int64_t)p.n_slots * B,
+                  (int64_t)desc_host[H_NSPLIT] * B, (int64_t)desc_host[H_NUNIFORM] * B, workspace, (hipStream_t)stream);
+}
+
+extern "C" int64_t sdag_attn_batch_workspace_bytes(const int32_t* bt, int Hq, int Hkv) {
+    if (!batch_ok(bt) || Hq <= 0 || Hkv <= 0) return -1;
+    return workspace_bytes(bt[BT_NSLOTS], bt[BT_NUNIFORM], bt[BT_B], Hq, Hkv);
+}
+
+extern "C" int sdag_attn_fwd_batch(const void* q, const void* k, const void* v, void* o,
+                                   int64_t q_sb, int64_t q_sh, int64_t q_sl,
+                                   int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                   int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                                   int64_t o_sb, int64_t o_sl, int64_t o_sh,
+                                   int B, int Hq, int Hkv, int Lmax, int Dh, float scale,
+                                   const int32_t* batch_host, const int32_t* batch_dev,
+                                   void* workspace, int64_t workspace_bytes_, int out_dtype, void* stream) {
+    const Tensors t = {q, k, v, o, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sl, o_sh};
+    if (int rc = check_common(t, B, Hq, Hkv, Lmax, Dh, scale, out_dtype)) return rc;
+    if (!batch_ok(batch_host)) return fail(SDAG_ERR_DESC, "batch_host is not a batch table");
+    if (!batch_dev) return fail(SDAG_ERR_ARG, "batch_dev is NULL");
+    if (batch_host[BT_B] != B) return fail(SDAG_ERR_DESC, "batch table holds %d sequences, call has B=%d", batch_host[BT_B], B);
+    if (batch_host[BT_LMAX] > Lmax) return fail(SDAG_ERR_DESC, "a sequence of the batch has L=%d > Lmax=%d", batch_host[BT_LMAX], Lmax);
+    const int64_t need = sdag_attn_batch_workspace_bytes(batch_host, Hq, Hkv);
+    if (need > 0 && (!workspace || workspace_bytes_ < need)) return fail(SDAG_ERR_CAPACITY, "workspace needs %lld bytes", (long long)need);
+    AttnParams p;
+    p.desc = nullptr;
+    p.btab = batch_dev;
+    p.n_units = 0;
+    p.n_slots = 0;
+    p.L = 0;
+    p.off_units = batch_host[BT_OFF_PAIRS];
+    p.off_items = p.off_masks = 0;
+    return launch(p, t, B, Hq, Hkv, scale, out_dtype, batch_host[BT_NPAIRS], batch_host[BT_NSLOTS], batch_host[BT_NMERGE],
+                  batch_host[BT_NUNIFORM], workspace, (hipStream_t)stream);
 }
 
 extern "C" int sdag_mask_materialize(const int32_t* desc_host, const int32_t* desc_dev, uint8_t* out_dev, void* stream) {

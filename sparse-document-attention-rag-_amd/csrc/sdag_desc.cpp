@@ -119,7 +119,7 @@ int emit(int L, const FillFn& fill, int max_items_per_unit, int32_t* out, int64_
     std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& c) { return (a.e - a.b) > (c.e - c.b); });
 
     int64_t off = H_WORDS;
-    const int64_t off_units = off;  off += (int64_t)units.size() * 4;
+    const int64_t off_units = off;  off += (int64_t)units.size() * UNIT_WORDS;
     const int64_t off_items = off;  off += (int64_t)n_items * 2;
     if (off & 1) ++off;
     const int64_t off_masks = off;  off += (int64_t)masks.size() * 2;
@@ -153,8 +153,12 @@ int emit(int L, const FillFn& fill, int max_items_per_unit, int32_t* out, int64_
     out[H_PAIRS_LO] = (int32_t)(uint32_t)(pairs & 0xffffffffll);
     out[H_PAIRS_HI] = (int32_t)(uint32_t)((uint64_t)pairs >> 32);
     for (size_t u = 0; u < units.size(); ++u) {
-        int32_t* p = out + off_units + u * 4;
+        int32_t* p = out + off_units + u * UNIT_WORDS;
         p[0] = units[u].rb; p[1] = units[u].b; p[2] = units[u].e; p[3] = units[u].slot;
+        p[4] = rbinfo[(size_t)units[u].rb * 2];
+        p[5] = items[(size_t)units[u].b * 2];
+        p[6] = items[(size_t)units[u].b * 2 + 1];
+        p[7] = 0;
     }
     if (n_items) std::memcpy(out + off_items, items.data(), sizeof(int32_t) * items.size());
     if (off_masks > off_items + (int64_t)n_items * 2) out[off_masks - 1] = 0;
@@ -239,5 +243,94 @@ extern "C" int sdag_desc_stats(const int32_t* d, int64_t* allowed_pairs, int32_t
     if (n_units) *n_units = d[H_NUNITS];
     if (n_items) *n_items = d[H_NITEMS];
     if (n_partial_tiles) *n_partial_tiles = d[H_NMASKS];
+    return SDAG_OK;
+}
+
+extern "C" int sdag_batch_build(const int32_t* const* descs, int B, int32_t* out, int64_t cap_words, int64_t* n_words) {
+    if (B <= 0 || !descs) return fail(SDAG_ERR_ARG, "bad batch");
+    for (int b = 0; b < B; ++b)
+        if (!desc_ok(descs[b])) return fail(SDAG_ERR_DESC, "sequence %d: not a descriptor", b);
+    struct Pair { int32_t b, unit, len; };
+    std::vector<Pair> pairs;
+    std::vector<int32_t> merge, uniform, slot_base(B), desc_off(B);
+    int64_t n_slots = 0;
+    int lmax = 0;
+    for (int b = 0; b < B; ++b) {
+        const int32_t* d = descs[b];
+        lmax = std::max(lmax, d[H_L]);
+        slot_base[b] = (int32_t)n_slots;
+        n_slots += d[H_NSLOTS];
+        const int32_t* u = d + d[H_OFF_UNITS];
+        for (int i = 0; i < d[H_NUNITS]; ++i) pairs.push_back({b, i, u[UNIT_WORDS * i + 2] - u[UNIT_WORDS * i + 1]});
+        for (int e = 0; e < d[H_NSPLIT]; ++e) { merge.push_back(b); merge.push_back(e); }
+        const int32_t* un = d + d[H_OFF_UNIFORM];
+        for (int i = 0; i < d[H_NUNIFORM]; ++i) { uniform.push_back(b); uniform.push_back(un[i]); }
+    }
+    // Sequence-major order (units inside a descriptor are already longest first): the blocks that read one
+    // sequence's K/V run together, so those rows stay in the XCD's L2 while they are needed.
+    int64_t off = BT_WORDS;
+    const int64_t off_desc = off;     off += B;
+    const int64_t off_slot = off;     off += B;
+    const int64_t off_pairs = off;    off += (int64_t)pairs.size() * PAIR_WORDS;
+    const int64_t off_merge = off;    off += (int64_t)merge.size();
+    const int64_t off_uniform = off;  off += (int64_t)uniform.size();
+    // descriptors: one copy per distinct pointer, each at an even word offset (their masks are 64-bit words)
+    std::vector<const int32_t*> uniq;
+    for (int b = 0; b < B; ++b) {
+        size_t j = 0;
+        while (j < uniq.size() && uniq[j] != descs[b]) ++j;
+        if (j == uniq.size()) {
+            uniq.push_back(descs[b]);
+            if (off & 1) ++off;
+            desc_off[b] = (int32_t)off;
+            off += descs[b][H_TOTAL_WORDS];
+        } else {
+            for (int c = 0; c < b; ++c)
+                if (descs[c] == descs[b]) { desc_off[b] = desc_off[c]; break; }
+        }
+    }
+    const int64_t total = off;
+    if (n_words) *n_words = total;
+    if (total > 0x7fffffff || n_slots > 0x7fffffff) return fail(SDAG_ERR_ARG, "batch table too large");
+    if (!out || cap_words < total) return fail(SDAG_ERR_CAPACITY, "batch table needs %lld words, buffer has %lld", (long long)total, (long long)cap_words);
+    std::memset(out, 0, sizeof(int32_t) * (size_t)total);
+    out[BT_MAGIC] = BATCH_MAGIC;
+    out[BT_VERSION] = 1;
+    out[BT_B] = B;
+    out[BT_NPAIRS] = (int32_t)pairs.size();
+    out[BT_NMERGE] = (int32_t)(merge.size() / 2);
+    out[BT_NUNIFORM] = (int32_t)(uniform.size() / 2);
+    out[BT_NSLOTS] = (int32_t)n_slots;
+    out[BT_OFF_DESC] = (int32_t)off_desc;
+    out[BT_OFF_SLOTBASE] = (int32_t)off_slot;
+    out[BT_OFF_PAIRS] = (int32_t)off_pairs;
+    out[BT_OFF_MERGE] = (int32_t)off_merge;
+    out[BT_OFF_UNIFORM] = (int32_t)off_uniform;
+    out[BT_TOTAL_WORDS] = (int32_t)total;
+    out[BT_LMAX] = lmax;
+    for (int b = 0; b < B; ++b) {
+        out[off_desc + b] = desc_off[b];
+        out[off_slot + b] = slot_base[b];
+    }
+    for (size_t i = 0; i < pairs.size(); ++i) {
+        const int b = pairs[i].b;
+        const int32_t* dsc = descs[b];
+        const int32_t* u = dsc + dsc[H_OFF_UNITS] + (size_t)pairs[i].unit * UNIT_WORDS;
+        int32_t* r = out + off_pairs + i * PAIR_WORDS;
+        r[0] = b;
+        r[1] = u[0];
+        r[2] = u[1];
+        r[3] = u[2];
+        r[4] = u[3] < 0 ? -1 : slot_base[b] + u[3];
+        r[5] = u[4];
+        r[6] = dsc[H_L];
+        r[7] = u[5];
+        r[8] = u[6];
+        r[9] = desc_off[b] + dsc[H_OFF_ITEMS];
+        r[10] = desc_off[b] + dsc[H_OFF_MASKS];
+    }
+    if (!merge.empty()) std::memcpy(out + off_merge, merge.data(), sizeof(int32_t) * merge.size());
+    if (!uniform.empty()) std::memcpy(out + off_uniform, uniform.data(), sizeof(int32_t) * uniform.size());
+    for (int b = 0; b < B; ++b) std::memcpy(out + desc_off[b], descs[b], sizeof(int32_t) * (size_t)descs[b][H_TOTAL_WORDS]);
     return SDAG_OK;
 }

@@ -12,7 +12,7 @@ from typing import Dict, Optional
 import torch
 
 from . import _lib
-from .descriptor import Descriptor
+from .descriptor import BatchDescriptor, Descriptor
 
 _workspaces: Dict[torch.device, torch.Tensor] = {}
 
@@ -114,3 +114,53 @@ class BoundAttention:
         rc = self._fn(*self._args, _lib.stream_ptr(self.device) if stream is None else stream)
         if rc:
             _lib.check(rc)
+
+
+class BoundBatchAttention:
+    """Masked prefill attention of B sequences, each with its own descriptor, in one launch on bound tensors.
+
+    query [B, Hq, Lmax, D], key / value [B, Hkv, Lmax, D], out [B, Lmax, Hq, D]; sequence b uses rows
+    [0, L_b) of its slice (L_b from its descriptor); rows beyond L_b are left untouched in ``out``.
+    """
+
+    def __init__(self, query, key, value, batch: BatchDescriptor, out: torch.Tensor, scaling: Optional[float] = None):
+        B, Hq, L, D = query.shape
+        Hkv = key.shape[1]
+        if query.dtype != torch.bfloat16 or key.dtype != torch.bfloat16 or value.dtype != torch.bfloat16:
+            raise TypeError("bf16 query/key/value expected")
+        if query.stride(3) != 1 or key.stride(3) != 1 or value.stride(3) != 1 or out.stride(3) != 1:
+            raise ValueError("head_dim must be contiguous")
+        if key.shape != value.shape or key.shape[0] != B or key.shape[2] != L or key.shape[3] != D:
+            raise ValueError("shape mismatch")
+        if out.shape != (B, L, Hq, D) or out.dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("bad out tensor")
+        if batch.B != B or batch.Lmax > L:
+            raise ValueError("batch descriptor does not match the tensors")
+        self.device = query.device
+        self._keep = (query, key, value, out, batch)
+        ws = _workspace(self.device, batch.workspace_bytes(Hq, Hkv))
+        self._fn = _lib.lib().sdag_attn_fwd_batch
+        self._args = (
+            query.data_ptr(), key.data_ptr(), value.data_ptr(), out.data_ptr(),
+            query.stride(0), query.stride(1), query.stride(2),
+            key.stride(0), key.stride(1), key.stride(2),
+            value.stride(0), value.stride(1), value.stride(2),
+            out.stride(0), out.stride(1), out.stride(2),
+            B, Hq, Hkv, L, D, float(D ** -0.5 if scaling is None else scaling),
+            batch.host_ptr, batch.device(self.device).data_ptr(),
+            ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+            _lib.OUT_F32 if out.dtype == torch.float32 else _lib.OUT_BF16)
+
+    def __call__(self, stream: Optional[int] = None) -> None:
+        rc = self._fn(*self._args, _lib.stream_ptr(self.device) if stream is None else stream)
+        if rc:
+            _lib.check(rc)
+
+
+def sdag_attention_batch(query, key, value, batch: BatchDescriptor, scaling: Optional[float] = None,
+                         out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """One-shot form of ``BoundBatchAttention``; rows beyond each sequence's length come back as zeros."""
+    B, Hq, L, D = query.shape
+    out = torch.zeros((B, L, Hq, D), dtype=out_dtype, device=query.device)
+    BoundBatchAttention(query, key, value, batch, out, scaling)()
+    return out

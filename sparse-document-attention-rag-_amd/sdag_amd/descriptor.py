@@ -156,3 +156,42 @@ def from_dense(mask, max_items_per_unit: int = 0) -> Descriptor:
         return lib.sdag_desc_from_dense(m.ctypes.data, m.shape[0], int(max_items_per_unit), out_ptr, cap, need)
 
     return Descriptor(_run_builder(call))
+
+
+class BatchDescriptor:
+    """Descriptors of several sequences packed for one launch (``sdag_attn_fwd_batch``)."""
+
+    def __init__(self, descs: Sequence[Descriptor]):
+        if not descs:
+            raise ValueError("empty batch")
+        self.descs = list(descs)
+        ptrs = (ctypes.c_void_p * len(descs))(*[d.host_ptr for d in descs])
+        lib = _lib.lib()
+
+        def call(out_ptr, cap, need):
+            return lib.sdag_batch_build(ptrs, len(descs), out_ptr, cap, need)
+
+        self.host = _run_builder(call)
+        self._dev: Dict[torch.device, torch.Tensor] = {}
+        self.B = len(descs)
+        self.Lmax = max(d.L for d in descs)
+
+    @property
+    def host_ptr(self) -> int:
+        return self.host.ctypes.data
+
+    def device(self, device) -> torch.Tensor:
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        t = self._dev.get(device)
+        if t is None:
+            t = torch.from_numpy(self.host).to(device)
+            self._dev[device] = t
+        return t
+
+    def workspace_bytes(self, Hq: int, Hkv: int) -> int:
+        n = _lib.lib().sdag_attn_batch_workspace_bytes(self.host_ptr, Hq, Hkv)
+        if n < 0:
+            raise _lib.SdagError(-1, "bad workspace query")
+        return int(n)

@@ -31,12 +31,13 @@ def expand_descriptor(words):
     w = np.asarray(words, dtype=np.int32)
     L = int(w[H["L"]])
     out = np.zeros((L, L), dtype=bool)
-    units = w[w[H["OFF_UNITS"]]: w[H["OFF_UNITS"]] + 4 * w[H["NUNITS"]]].reshape(-1, 4)
+    units = w[w[H["OFF_UNITS"]]: w[H["OFF_UNITS"]] + 8 * w[H["NUNITS"]]].reshape(-1, 8)
     items = w[w[H["OFF_ITEMS"]]: w[H["OFF_ITEMS"]] + 2 * w[H["NITEMS"]]].reshape(-1, 2)
     masks = w[w[H["OFF_MASKS"]]: w[H["OFF_MASKS"]] + 64 * w[H["NMASKS"]]].view(np.uint64).reshape(-1, 32)
     cols = np.arange(64, dtype=np.uint64)
     seen = set()
-    for rb, b, e, slot in units:
+    for rb, b, e, slot, uni, kt0, mi0, _ in units:
+        assert (kt0, mi0) == tuple(items[b])
         for it in range(b, e):
             assert it not in seen
             seen.add(it)

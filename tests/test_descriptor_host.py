@@ -28,7 +28,7 @@ def test_unit_structure():
     for T in (0, 4, 8, 1000):
         d = sdag_amd.from_spans(L, 60, spans, qa, None, max_items_per_unit=T)
         w = d.host
-        units = w[w[H["OFF_UNITS"]]: w[H["OFF_UNITS"]] + 4 * w[H["NUNITS"]]].reshape(-1, 4)
+        units = w[w[H["OFF_UNITS"]]: w[H["OFF_UNITS"]] + 8 * w[H["NUNITS"]]].reshape(-1, 8)
         lens = units[:, 2] - units[:, 1]
         assert (lens > 0).all() and (np.diff(lens) <= 0).all()          # longest units first
         if T > 0:

@@ -281,3 +281,38 @@ def test_generate_with_custom_mask_on_gpu():
                 assert text == bytes(z["greedy_text"]).decode()
     finally:
         SDAG.TEMPERATURE = old_t
+
+
+def test_attention_batch_of_different_prompts():
+    """One launch over sequences with different lengths, spans and neighbours, against the per-sequence oracle."""
+    import sdag_amd
+    from oracle import sdag_ref
+
+    cases = [
+        synthetic_layout(9, [40, 0, 75, 33], 2, 17) + (9, [[2], [0], [3, 0], [1]]),
+        synthetic_layout(21, [100, 130], 1, 40) + (21, None),
+        synthetic_layout(5, [300, 280, 310], 1, 25) + (5, [[1], [2], [0]]),
+        ([], 50, 50, 50, None),                       # plain causal prompt without documents
+    ]
+    Lmax = max(c[2] for c in cases) + 7
+    B, Hq, Hkv = len(cases), 8, 2
+    g = torch.Generator().manual_seed(21)
+    q = torch.randn(B, Hq, Lmax, 128, generator=g).to(torch.bfloat16)
+    k = torch.randn(B, Hkv, Lmax, 128, generator=g).to(torch.bfloat16)
+    v = torch.randn(B, Hkv, Lmax, 128, generator=g).to(torch.bfloat16)
+    descs = [sdag_amd.from_spans(L, sl, spans, qa, nbr, max_items_per_unit=3) for spans, qa, L, sl, nbr in cases]
+    batch = sdag_amd.BatchDescriptor(descs)
+    o = sdag_amd.sdag_attention_batch(q.to(DEV), k.to(DEV), v.to(DEV), batch, out_dtype=torch.float32).cpu()
+    for b, (spans, qa, L, sl, nbr) in enumerate(cases):
+        mask = torch.from_numpy(sdag_ref.mask_from_spans(L, sl, spans, qa, nbr))
+        ref = sdag_ref.masked_attention(q[b:b + 1, :, :L], k[b:b + 1, :, :L], v[b:b + 1, :, :L], mask, 128 ** -0.5)
+        assert _rel_err(o[b:b + 1, :L], ref) <= 1e-3, b
+        assert (o[b, L:] == 0).all()                 # rows past the sequence are not written
+    # the same descriptor object for every sequence is stored once
+    shared = sdag_amd.BatchDescriptor([descs[2]] * 3)
+    assert shared.host.size < 2 * descs[2].host.size
+    o2 = sdag_amd.sdag_attention_batch(q[:3].to(DEV), k[:3].to(DEV), v[:3].to(DEV), shared, out_dtype=torch.float32).cpu()
+    L = cases[2][2]
+    single = sdag_amd.sdag_attention(q[:3, :, :L].contiguous().to(DEV), k[:3, :, :L].contiguous().to(DEV),
+                                     v[:3, :, :L].contiguous().to(DEV), descs[2], out_dtype=torch.float32).cpu()
+    assert torch.equal(o2[:, :L], single)

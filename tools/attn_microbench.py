@@ -40,11 +40,31 @@ if __name__ == "__main__":
         print(f"causal L={L}: {timeit(d, L, reps=2, nbuf=2):.1f} us", flush=True)
     if which == "batch":
         spans, qa, L = layout(60, 10, 300, 1, 30)
-        for B in (1, 2, 4, 8, 16, 32):
-            for T in (11, 64):
+        for B in ((32,) if "quick" in sys.argv else (1, 2, 4, 8, 16, 32)):
+            for T in ((64,) if "quick" in sys.argv else (11, 64)):
                 d = sdag_amd.from_spans(L, 60, spans, qa, None, max_items_per_unit=T)
                 t = timeit(d, L, reps=5, nbuf=2, B=B)
                 print(f"cfg3 B={B} T={T}: {t:.1f} us/launch = {t / B:.1f} us/query-layer", flush=True)
+    if which == "vbatch":
+        spans, qa, L = layout(60, 10, 300, 1, 30)
+        for B in ((32,) if "quick" in sys.argv else (8, 32)):
+            for T in ((64,) if "quick" in sys.argv else (11, 16, 32, 64)):
+                descs = [sdag_amd.from_spans(L, 60, spans, qa, None, max_items_per_unit=T) for _ in range(B)]
+                if len(sys.argv) > 2 and sys.argv[2] == "same":
+                    descs = [descs[0]] * B
+                bd = sdag_amd.BatchDescriptor(descs)
+                q = torch.randn((B, L, 32, 128), device=dev).to(torch.bfloat16).transpose(1, 2)
+                k = torch.randn((B, L, 8, 128), device=dev).to(torch.bfloat16).transpose(1, 2)
+                v = torch.randn((B, L, 8, 128), device=dev).to(torch.bfloat16).transpose(1, 2)
+                o = torch.empty((B, L, 32, 128), device=dev, dtype=torch.bfloat16)
+                call = sdag_amd.BoundBatchAttention(q, k, v, bd, o)
+                call(); torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5): call()
+                e1.record(); torch.cuda.synchronize()
+                t = e0.elapsed_time(e1) * 1e3 / 5
+                print(f"cfg3 own-descriptor batch B={B} T={T}: {t:.1f} us/launch = {t / B:.1f} us/query-layer", flush=True)
     if which in ("all", "causal"):
         for L in (64, 512, 4096):
             for T in (100000, 8):
