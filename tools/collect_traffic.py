@@ -3,7 +3,7 @@
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts 128-byte fabric read requests as 64 bytes
 for wide (16 B per lane) coalesced reads, so the read side is doubled; WRITE_SIZE is taken as reported.
-usage: collect_traffic.py <fetch_csv> <write_csv> <out_json>
+usage: collect_traffic.py <fetch_csv> <write_csv> <out_json> [mode]
 """
 import collections
 import csv
@@ -25,7 +25,7 @@ def per_kernel(path, counter):
     return {k: (tot[k] / n[k], n[k]) for k in tot}
 
 
-def main(fetch_csv, write_csv, out):
+def main(fetch_csv, write_csv, out, mode="batched"):
     f = per_kernel(fetch_csv, "FETCH_SIZE")
     w = per_kernel(write_csv, "WRITE_SIZE")
     res = {}
@@ -35,11 +35,17 @@ def main(fetch_csv, write_csv, out):
         res[k] = {"launches": max(nf, nw), "fetch_size_kib_raw": fk, "write_size_kib_raw": wk,
                   "read_bytes_corrected": 2 * fk * 1024, "write_bytes": wk * 1024,
                   "hbm_bytes_per_launch": 2 * fk * 1024 + wk * 1024}
+    try:
+        prev = json.load(open(out))
+    except Exception:
+        prev = {}
+    prev[mode] = res
     if "sdag_attn_main" in res:
-        res["sdag_attn_main_bytes_per_launch"] = res["sdag_attn_main"]["hbm_bytes_per_launch"]
+        prev["sdag_attn_main_bytes_per_launch_" + mode] = res["sdag_attn_main"]["hbm_bytes_per_launch"]
+    res = prev
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
