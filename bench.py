@@ -129,14 +129,21 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_REHEARSE_ON_ONE_GPU=1: every rank uses GPU 0 and the timing barrier runs over gloo, to rehearse the
+    # multi-rank control flow on a one-GPU box (numbers from such a run are meaningless).
+    rehearse = os.environ.get("BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import sdag_amd
 
@@ -208,7 +215,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
