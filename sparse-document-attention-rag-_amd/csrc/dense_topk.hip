@@ -261,8 +261,11 @@ __device__ __forceinline__ void wave_select(float s, int64_t id, int k, int lane
     }
 }
 
+constexpr int MRG_THREADS = 1024;
+constexpr int MRG_WAVES = MRG_THREADS / 64;
+
 template <typename IdT>
-__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ in_s, const IdT* __restrict__ in_i,
+__global__ __launch_bounds__(MRG_THREADS) void topk_merge_kernel(const float* __restrict__ in_s, const IdT* __restrict__ in_i,
                                                          int n_parts, int nq, int q_stride, int k, int64_t id_base,
                                                          float* __restrict__ out_s, int64_t* __restrict__ out_i) {
     __shared__ float a_s[MRG_A];
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
     const int M = n_parts * k;
     // level 0: global -> A.  Entry e = part * k + t lives at in[(part * q_stride + q) * k + t].
     int nch = (M + 63) / 64;
-    for (int c = w; c < nch; c += 4) {
+    for (int c = w; c < nch; c += MRG_WAVES) {
         const int e = c * 64 + lane;
         float s = -INFINITY;
         int64_t id = -1;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
         float* dsd = in_a ? b_s : a_s;
         int64_t* did = in_a ? b_i : a_i;
         const int nch2 = (n + 63) / 64;
-        for (int c = w; c < nch2; c += 4) {
+        for (int c = w; c < nch2; c += MRG_WAVES) {
             const int e = c * 64 + lane;
             const float s = e < n ? ss[e] : -INFINITY;
             const int64_t id = e < n ? si[e] : -1;
@@ -392,7 +395,7 @@ extern "C" int sdag_dense_topk(const float* Q, int nq, const float* C, int64_t N
                                pl.rows_per_wg, part_s, part_i);
             SDAG_HIP_CHECK(hipGetLastError());
         }
-        hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(256), 0, st, part_s, part_i, N > 0 ? pl.n_wg : 0, nqt, QT,
+        hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, part_s, part_i, N > 0 ? pl.n_wg : 0, nqt, QT,
                            k, id_base, out_s + (int64_t)q0 * k, out_i + (int64_t)q0 * k);
         SDAG_HIP_CHECK(hipGetLastError());
     }
@@ -406,7 +409,7 @@ extern "C" int sdag_topk_merge(const float* in_s, const int64_t* in_i, int n_par
     if (nq == 0) return SDAG_OK;
     if (!out_s || !out_i || (n_parts > 0 && (!in_s || !in_i))) return fail(SDAG_ERR_ARG, "NULL pointer");
     if ((((int64_t)n_parts * k + 63) / 64) * k > MRG_A) return fail(SDAG_ERR_ARG, "too many partial lists");
-    hipLaunchKernelGGL(topk_merge_kernel<int64_t>, dim3(nq), dim3(256), 0, (hipStream_t)stream, in_s, in_i, n_parts, nq, nq, k,
+    hipLaunchKernelGGL(topk_merge_kernel<int64_t>, dim3(nq), dim3(MRG_THREADS), 0, (hipStream_t)stream, in_s, in_i, n_parts, nq, nq, k,
                        (int64_t)0, out_s, out_i);
     SDAG_HIP_CHECK(hipGetLastError());
     return SDAG_OK;

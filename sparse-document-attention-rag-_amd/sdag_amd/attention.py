@@ -139,6 +139,7 @@ class BoundBatchAttention:
         self.device = query.device
         self._keep = (query, key, value, out, batch)
         ws = _workspace(self.device, batch.workspace_bytes(Hq, Hkv))
+        self._ws = ws  # keeps the scratch alive even if the per-device cache is later replaced by a larger one
         self._fn = _lib.lib().sdag_attn_fwd_batch
         self._args = (
             query.data_ptr(), key.data_ptr(), value.data_ptr(), out.data_ptr(),

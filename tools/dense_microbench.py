@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Event-timed runs of the exact inner-product search (diagnostic, GPU only)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sparse-document-attention-rag-_amd")); sys.path.insert(0, ROOT)
+import torch, sdag_amd
+dev = torch.device("cuda:0")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+C = torch.empty((N, d), device=dev)
+for lo in range(0, N, 1 << 18):
+    x = torch.randn((min(N, lo + (1 << 18)) - lo, d), device=dev); C[lo:lo + x.shape[0]] = x / x.norm(dim=1, keepdim=True)
+idx = sdag_amd.FlatIPIndex(d, device=dev); idx._corpus = C
+for nq in (32, 64):
+    Q = torch.randn((nq, d), device=dev); Q = Q / Q.norm(dim=1, keepdim=True)
+    idx.search_device(Q, 10); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): idx.search_device(Q, 10)
+    e1.record(); torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / reps
+    print(f"N={N} d={d} nq={nq}: {t:.3f} ms/search  {N * d * 4 / t / 1e9 * (nq / 32 if nq > 32 else 1):.2f} TB/s-equivalent scan, {nq / t * 1e3:.0f} q/s", flush=True)
