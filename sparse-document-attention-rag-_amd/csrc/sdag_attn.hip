@@ -26,6 +26,10 @@
 
 #include "common.h"
 
+#ifndef SDAG_ABLATE
+#define SDAG_ABLATE 0
+#endif
+
 namespace sdag {
 #ifdef SDAG_STAMPS
 __device__ unsigned long long g_stamps[16];
@@ -47,6 +51,7 @@ constexpr int RB = 32;            // query rows per workgroup (one MFMA tile)
 constexpr int KT = 64;            // keys per tile
 constexpr int TILE_BYTES = KT * D * 2;
 constexpr int VSUM_CHUNKS = 32;   // column-sum partials per (batch, kv head)
+constexpr float RESCALE_LOG2 = 8.0f;  // the running maximum may lag the true one by up to 2^8
 
 struct AttnParams {
     const unsigned short* q;
@@ -345,7 +350,9 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         uint64_t mrow_nxt = ~0ull;
         if (has_next) {
             if (mi_nxt >= 0) mrow_nxt = masks[(int64_t)mi_nxt * RB + r];
+#if !(SDAG_ABLATE & 1)
             stage_load(kt_nxt);
+#endif
         }
         // unconditional (index clamped to the unit's last item) so that no branch copies the loaded registers
         const int it2 = min(it + 2, it_end - 1);
@@ -373,6 +380,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
         }
+#if !(SDAG_ABLATE & 2)
         {
             bf16x8 ka[8], kb2[8];
 #pragma unroll
@@ -394,6 +402,10 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
         }
+#else
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0[i] += __builtin_bit_cast(float, (unsigned)qf[i & 7][0] << 16) ; s1[i] += (float)i; }
+#endif
 
         STAMP(1);
         STAMP(2);
@@ -408,65 +420,76 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
             restage_v_scaled(cur, kt_cur, ve);
             __syncthreads();
         }
-        // ---- online softmax (per query = per lane, halves combined by one exchange)
+        // ---- online softmax (per query = per lane, halves combined by one exchange).  The running maximum is only
+        // raised when some row's maximum grew by more than 2^RESCALE_LOG2 (or became finite for the first time):
+        // until then probabilities may exceed 1 by at most that factor, which fp16 holds at full relative
+        // precision, and the 64-register rescale of O is skipped.  A scaled V tile (ve > 0) always takes the exact
+        // maximum so that p * 2^ve stays inside fp16.
         float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
         for (int i = 1; i < 16; ++i) mx = max3(mx, s0[i], s1[i]);
         mx = half_max(mx);
         const float m_new = fmaxf(m_run, mx);
-        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = fast_exp2((m_run - m_safe) * c);
+        const bool grow = (m_new - m_run) * c > RESCALE_LOG2;  // -inf -> finite: true; -inf -> -inf: NaN, false
+        const bool rescale = __builtin_amdgcn_ballot_w64(grow) != 0 || ve > 0;
+        const float m_use = rescale ? m_new : m_run;
+        const float m_safe = (m_use == -INFINITY) ? 0.f : m_use;
+        const float alpha = rescale ? fast_exp2((m_run - m_safe) * c) : 1.0f;
         const float nb = (float)ve - m_safe * c;  // probabilities carry 2^ve when V was scaled by 2^-ve
-        {
-            const f32x2 c2 = {c, c}, nb2 = {nb, nb};
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                f32x2 a = {s0[i], s0[i + 1]}, b2 = {s1[i], s1[i + 1]};
-                a = __builtin_elementwise_fma(a, c2, nb2);    // v_pk_fma_f32: two scaled scores per instruction
-                b2 = __builtin_elementwise_fma(b2, c2, nb2);
-                s0[i] = fast_exp2(a[0]); s0[i + 1] = fast_exp2(a[1]);
-                s1[i] = fast_exp2(b2[0]); s1[i + 1] = fast_exp2(b2[1]);
-            }
+        for (int i = 0; i < 16; ++i) {
+#if !(SDAG_ABLATE & 8)
+            s0[i] = fast_exp2(__builtin_fmaf(s0[i], c, nb));
+            s1[i] = fast_exp2(__builtin_fmaf(s1[i], c, nb));
+#else
+            s0[i] = __builtin_fmaf(s0[i], c, nb);
+            s1[i] = __builtin_fmaf(s1[i], c, nb);
+#endif
         }
 
         // ---- P^T fragments in fp16: registers 8 s .. 8 s + 7 of block kb are k-step (kb, s) of the B operand.
-        // The row sum is taken over the ROUNDED probabilities, the values the MFMA multiplies with, so that
-        // the output stays an exact convex combination of V rows: the rounding error of a dominant key then
-        // cancels against the normaliser instead of scaling the whole row.
+        // Round-toward-zero packing (one instruction per pair); the row sum is taken over the ROUNDED
+        // probabilities, the values the MFMA multiplies with, so that the output stays an exact convex
+        // combination of V rows and the rounding (bias included) cancels against the normaliser.
         f16x8 pf[2][2];
         float rs0 = 0.f, rs1 = 0.f;
         const f16x2 ones = {(_Float16)1.0f, (_Float16)1.0f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f16x2 t;
-            t[0] = (_Float16)s0[2 * j]; t[1] = (_Float16)s0[2 * j + 1];
+            t = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(s0[2 * j], s0[2 * j + 1]));
             pf[0][0][2 * j] = t[0]; pf[0][0][2 * j + 1] = t[1];
             rs0 = __builtin_amdgcn_fdot2(t, ones, rs0, false);
-            t[0] = (_Float16)s0[8 + 2 * j]; t[1] = (_Float16)s0[8 + 2 * j + 1];
+            t = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(s0[8 + 2 * j], s0[8 + 2 * j + 1]));
             pf[0][1][2 * j] = t[0]; pf[0][1][2 * j + 1] = t[1];
             rs1 = __builtin_amdgcn_fdot2(t, ones, rs1, false);
-            t[0] = (_Float16)s1[2 * j]; t[1] = (_Float16)s1[2 * j + 1];
+            t = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(s1[2 * j], s1[2 * j + 1]));
             pf[1][0][2 * j] = t[0]; pf[1][0][2 * j + 1] = t[1];
             rs0 = __builtin_amdgcn_fdot2(t, ones, rs0, false);
-            t[0] = (_Float16)s1[8 + 2 * j]; t[1] = (_Float16)s1[8 + 2 * j + 1];
+            t = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(s1[8 + 2 * j], s1[8 + 2 * j + 1]));
             pf[1][1][2 * j] = t[0]; pf[1][1][2 * j + 1] = t[1];
             rs1 = __builtin_amdgcn_fdot2(t, ones, rs1, false);
         }
         float rs = rs0 + rs1;
         rs = half_sum(rs);
         if (ve > 0) rs *= __uint_as_float((unsigned)(127 - ve) << 23);
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+        if (rescale) {
+            l_run = l_run * alpha + rs;
+            m_run = m_new;
+            if (it != it_begin) {  // O is still zero on the unit's first tile
 #pragma unroll
-            for (int db = 0; db < 4; ++db)
+                for (int db = 0; db < 4; ++db)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
+                    for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
+            }
+        } else {
+            l_run += rs;
         }
 
         STAMP(3);
         // ---- O^T += V^T P^T.  The transposed reads of one 32-column block of V run ahead of the four MFMAs of the
         // previous block.
+#if !(SDAG_ABLATE & 4)
         {
             s16x4 va[4][4][2];
 #pragma unroll
@@ -500,9 +523,17 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 6, 1);
         }
+#else
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) asm volatile("" ::"v"(pf[kb][s]));
+#endif
 
         STAMP(4);
+#if !(SDAG_ABLATE & 1)
         if (has_next) stage_store(cur ^ 1, seq + 1u);
+#endif
         STAMP(5);
         __syncthreads();
         STAMP(6);
