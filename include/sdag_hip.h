@@ -50,19 +50,22 @@ const char* sdag_last_error(void);
  *   nbr_off    n_docs + 1 offsets into nbr_idx, or NULL for "no neighbours" (the reference's
  *              doc_neighbors=None, and also its len(doc_neighbors) != num_docs case, SDAG.py:111)
  *   nbr_idx    neighbour document ids; ids outside [0, n_docs) are skipped (SDAG.py:119-120)
- *   max_items_per_unit  longest run of key tiles one workgroup walks before the row block is split
- *              into several units that are merged afterwards; 0 picks a default from the layout
+ *   max_items_per_unit  longest run of key tiles walked for one row block before it is split into
+ *              several units that are merged afterwards; 0 picks a default from the layout
+ *   n_streams  the units are dealt to this many work streams; the attention launch starts one persistent
+ *              workgroup per stream and group of (up to 4) query heads sharing a key/value head.  0 = 64,
+ *              which fills 256 compute units at 2 workgroups each when Hkv * ceil(Hq / Hkv / 4) = 8
  *   out        caller buffer of cap_words int32 words (may be NULL to query the size)
  *   n_words    receives the number of words the descriptor needs
  * Returns SDAG_ERR_CAPACITY when cap_words is too small (n_words is still set).
  */
 int sdag_desc_build(int L, int sys_user_len, int n_docs, const int32_t* spans, int qa_start,
                     const int32_t* nbr_off, const int32_t* nbr_idx, int max_items_per_unit,
-                    int32_t* out, int64_t cap_words, int64_t* n_words);
+                    int n_streams, int32_t* out, int64_t cap_words, int64_t* n_words);
 
 /* Same descriptor from an arbitrary dense mask (uint8 [L, L] on the host, nonzero = may attend), for
  * callers of generate_with_custom_mask() that bring their own prompt_mask (SDAG.py:130-136,167-171). */
-int sdag_desc_from_dense(const uint8_t* mask, int L, int max_items_per_unit, int32_t* out,
+int sdag_desc_from_dense(const uint8_t* mask, int L, int max_items_per_unit, int n_streams, int32_t* out,
                          int64_t cap_words, int64_t* n_words);
 
 /* Number of (row, column) pairs the descriptor allows, not counting uniform rows; n_uniform_rows may
@@ -105,11 +108,12 @@ int sdag_attn_fwd(const void* q, const void* k, const void* v, void* o,
  * run_rag_with_doc_isolation per query); batching the masked prefill of many queries is how this build fills
  * the GPU, so these entry points have no single call site to cite beyond SDAG.py:176.
  *
- * sdag_batch_build concatenates B host descriptors (the same pointer may repeat) with a table of
- * (sequence, unit) pairs in sequence-major order.  Tensors are padded to Lmax rows per sequence:
+ * sdag_batch_build concatenates B host descriptors (the same pointer may repeat) and deals their units, in
+ * sequence-major order, to n_streams work streams (0 = 64).  Tensors are padded to Lmax rows per sequence:
  * q [B, Hq, Lmax, D], k / v [B, Hkv, Lmax, D], o [B, Lmax, Hq, D] through the usual strides; rows at and
  * beyond a sequence's own length are neither read as queries nor written. */
-int sdag_batch_build(const int32_t* const* descs_host, int B, int32_t* out, int64_t cap_words, int64_t* n_words);
+int sdag_batch_build(const int32_t* const* descs_host, int B, int n_streams, int32_t* out, int64_t cap_words,
+                     int64_t* n_words);
 
 int64_t sdag_attn_batch_workspace_bytes(const int32_t* batch_host, int Hq, int Hkv);
 

@@ -22,9 +22,9 @@ int fail(int code, const char* fmt, ...);
 
 // ---- descriptor layout (int32 words) -------------------------------------------------------------
 // A descriptor describes one L x L "may attend" relation at a granularity of 32-row blocks and 64-key
-// tiles.  header | units | items | masks | rbinfo | split | uniform
+// tiles.  header | units | items | masks | rbinfo | split | uniform | lane masks | stream offsets | steps
 constexpr int32_t DESC_MAGIC = 0x47414453;  // "SDAG"
-constexpr int32_t DESC_VERSION = 2;
+constexpr int32_t DESC_VERSION = 3;
 enum : int {
     H_MAGIC = 0,
     H_VERSION = 1,
@@ -46,6 +46,11 @@ enum : int {
     H_NSLOTS = 17,  // partial-result slots (sum of units over split row blocks)
     H_PAIRS_LO = 18,
     H_PAIRS_HI = 19,
+    H_NSTREAMS = 20,     // work streams (one persistent workgroup per stream and key/value head slot)
+    H_NSTEPS = 21,       // steps over all streams (= items)
+    H_OFF_LMASKS = 22,   // multiple of 16 words
+    H_OFF_STREAMS = 23,  // n_streams + 1 step indices
+    H_OFF_STEPS = 24,    // multiple of 8 words
     H_WORDS = 32
 };
 // unit   : 8 words {row_block, item_begin, item_end, slot (-1 = writes the output itself), uniform_rows bits of the
@@ -56,12 +61,29 @@ constexpr int UNIT_WORDS = 8;
 // rbinfo : 2 words per row block {uniform_rows bits, reserved}
 // split  : 4 words {row_block, first_slot, n_slots, 0}
 // uniform: 1 word per row: its index
+// lane mask: the same 32 x 64 bits as a mask, regrouped for the attention kernel: 32 uint64, word 16 kb + i holds for
+//          accumulator register i of key block kb (keys 32 kb .. 32 kb + 31 of the tile) one bit per lane:
+//          bit (r + 32 h) = row r may attend key 32 kb + (i & 3) + 8 (i >> 2) + 4 h
+// stream : the units are dealt to n_streams work streams (greedy, least loaded first); a stream is a run of steps
+// step   : 8 words, one per (unit, item) in the order a workgroup walks them
+constexpr int STEP_WORDS = 8;
+enum : int {
+    S_KT = 0,     // key tile
+    S_MOFF = 1,   // word offset of the tile's lane mask from the start of the table, 0 = every pair allowed
+    S_FLAGS = 2,  // bit 0: first step of its unit, bit 1: last step of its unit
+    S_B = 3,      // sequence (0 in a single descriptor)
+    S_L = 4,      // length of that sequence
+    S_RB = 5,     // row block
+    S_SLOT = 6,   // partial-result slot (global inside a batch table) or -1
+    S_UBITS = 7   // rows of the row block that allow nothing
+};
+constexpr int DEFAULT_STREAMS = 64;
 
 // ---- batch table (int32 words): several sequences, each with its own descriptor, in one launch ------------
-// header | desc_off[B] | slot_base[B] | pairs (16 words each, sequence-major, longest units first inside: {sequence,
-// row_block, item_begin, item_end, global slot or -1, uniform_rows bits, L, first key tile, first mask index, word
-// offset of the sequence's items, word offset of its masks, 0...}) | merge {sequence, split index} |
-// uniform {sequence, row} | the descriptors themselves (each at an even word offset)
+// header | desc_off[B] | slot_base[B] | merge {sequence, split index} | uniform {sequence, row} | stream offsets |
+// steps (as in a descriptor, with S_B the sequence, S_SLOT global and S_MOFF relative to the table) | the
+// descriptors themselves (each at a multiple of 16 words).  Units are dealt to the streams in sequence-major
+// order, longest first inside a sequence, so the workgroups running at any time read the K/V of few sequences.
 constexpr int32_t BATCH_MAGIC = 0x54424453;  // "SDBT"
 enum : int {
     BT_MAGIC = 0,
@@ -73,15 +95,19 @@ enum : int {
     BT_NSLOTS = 6,
     BT_OFF_DESC = 7,
     BT_OFF_SLOTBASE = 8,
-    BT_OFF_PAIRS = 9,
+    BT_RESERVED9 = 9,
     BT_OFF_MERGE = 10,
     BT_OFF_UNIFORM = 11,
     BT_TOTAL_WORDS = 12,
     BT_LMAX = 13,
-    BT_WORDS = 16
+    BT_NSTREAMS = 14,
+    BT_NSTEPS = 15,
+    BT_OFF_STREAMS = 16,
+    BT_OFF_STEPS = 17,
+    BT_WORDS = 32
 };
-constexpr int PAIR_WORDS = 16;
-inline bool batch_ok(const int32_t* d) { return d && d[BT_MAGIC] == BATCH_MAGIC && d[BT_VERSION] == 1; }
+constexpr int32_t BATCH_VERSION = 2;
+inline bool batch_ok(const int32_t* d) { return d && d[BT_MAGIC] == BATCH_MAGIC && d[BT_VERSION] == BATCH_VERSION; }
 
 inline bool desc_ok(const int32_t* d) { return d && d[H_MAGIC] == DESC_MAGIC && d[H_VERSION] == DESC_VERSION; }
 

@@ -58,22 +58,23 @@ struct AttnParams {
     const unsigned short* k;
     const unsigned short* v;
     void* o;
-    int64_t q_sb, q_sh, q_sl;
-    int64_t k_sb, k_sh, k_sl;
-    int64_t v_sb, v_sh, v_sl;
-    int64_t o_sb, o_sl, o_sh;
+    int q_sb, q_sh, q_sl;  // element strides (each below 2^31; products are taken in 64 bits)
+    int k_sb, k_sh, k_sl;
+    int v_sb, v_sh, v_sl;
+    int o_sb, o_sl, o_sh;
     int B, Hq, Hkv;
     int G;        // query heads per kv head
     int HG;       // groups of 4 query heads per kv head
-    int n_units;
     int n_main_blocks;
     int out_f32;
     float c;      // scale * log2(e)
     const int32_t* desc;  // single descriptor shared by every batch element (btab == nullptr)
     const int32_t* btab;  // batch table + per-sequence descriptors (see common.h), or nullptr
+    const int32_t* tab;   // whichever of the two is set: the table the streams and steps live in
+    int n_streams;        // work streams of the table
+    int off_streams, off_steps;  // word offsets of the stream offsets and the step records in the table
     int n_slots;          // partial-result slots of the shared descriptor
-    int L;                // length of the shared descriptor
-    int off_units, off_items, off_masks;  // word offsets inside the shared descriptor / of the pair records in btab
+    int slots_per_b;      // shared descriptor: n_slots (slots of batch element b start at b * n_slots); batch table: 0
     float* part_o;   // [global slot][Hq][32][128]
     float* part_ml;  // [global slot][Hq][32][2]
     float* vsum;     // [B][Hkv][VSUM_CHUNKS][128]
@@ -143,7 +144,7 @@ __device__ void vsum_block(const AttnParams& p, int vb, unsigned char* smem) {
     const int rows_per = (L + VSUM_CHUNKS - 1) / VSUM_CHUNKS;
     const int r0 = chunk * rows_per, r1 = min(L, r0 + rows_per);
     const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const unsigned short* base = p.v + b * p.v_sb + kvh * p.v_sh + cq * 4;
+    const unsigned short* base = p.v + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh + cq * 4;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     for (int r = r0 + rl; r < r1; r += 8) {
         const uint2 w = *reinterpret_cast<const uint2*>(base + (int64_t)r * p.v_sl);
@@ -166,11 +167,26 @@ __device__ void vsum_block(const AttnParams& p, int vb, unsigned char* smem) {
     }
 }
 
+#define AS4 __attribute__((address_space(4)))
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(16))) unsigned int u32x16;
+
+// 0 where the lane's bit of the 64-bit lane mask (words 2 j, 2 j + 1 of m) is set, -inf where it is clear: one
+// v_cndmask with the mask in a scalar register pair.
+__device__ __forceinline__ float mask_init(const u32x16& m, int j) {
+    const uint64_t w = ((uint64_t)m[2 * j + 1] << 32) | m[2 * j];
+    return __builtin_amdgcn_inverse_ballot_w64(w) ? 0.f : -INFINITY;
+}
+
+// One persistent workgroup (4 waves) per (work stream, key/value head slot): it walks the stream's steps, each a
+// 32-row query block x one 64-key tile.  The steps of one unit (a row block and a run of its tiles) follow each
+// other; at a unit's last step the next unit's Q rows are requested, and the K/V tile of the following step is
+// always in flight, so the load -> compute chain is only exposed once per workgroup, not once per unit.
 __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     // K0 K1 V0 V1 tile images, then two words of V-range tags (one per V buffer)
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES + 16];
 
-    int bid = blockIdx.x;
+    const int bid = blockIdx.x;
     if (bid >= p.n_main_blocks) {
         vsum_block(p, bid - p.n_main_blocks, smem);
         return;
@@ -181,29 +197,14 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     const int n_hslots = p.Hkv * p.HG;
     const int hslot = bid % n_hslots;
     const int rest = bid / n_hslots;
-    // ---- the work record: everything needed to start loading comes from ONE 32/64-byte read whose address
-    // depends only on kernel arguments (no chain of dependent header reads).
-    int b, rb, it_begin, it_end, gslot, L, kt_first, mi_first;
-    unsigned uniform_bits;
-    const int32_t* __restrict__ items;
-    const uint64_t* __restrict__ masks;
-    if (p.btab) {  // batch of sequences, each with its own descriptor
-        const int32_t* __restrict__ rec = p.btab + p.off_units + (int64_t)rest * PAIR_WORDS;
-        b = rec[0]; rb = rec[1]; it_begin = rec[2]; it_end = rec[3]; gslot = rec[4];
-        uniform_bits = (unsigned)rec[5]; L = rec[6]; kt_first = rec[7]; mi_first = rec[8];
-        items = p.btab + rec[9];
-        masks = reinterpret_cast<const uint64_t*>(p.btab + rec[10]);
-    } else {
-        const int unit = rest % p.n_units;
-        b = rest / p.n_units;
-        const int32_t* __restrict__ rec = p.desc + p.off_units + unit * UNIT_WORDS;
-        rb = rec[0]; it_begin = rec[1]; it_end = rec[2];
-        gslot = rec[3] < 0 ? -1 : b * p.n_slots + rec[3];
-        uniform_bits = (unsigned)rec[4]; kt_first = rec[5]; mi_first = rec[6];
-        L = p.L;
-        items = p.desc + p.off_items;
-        masks = reinterpret_cast<const uint64_t*>(p.desc + p.off_masks);
-    }
+    const int strm = rest % p.n_streams;
+    const int bg = rest / p.n_streams;  // batch element when one descriptor serves the whole batch, else 0
+    // The table is read-only for the whole launch and every index into it is wave-uniform: scalar loads.
+    const AS4 int32_t* tab = (const AS4 int32_t*)p.tab;
+    const int s_begin = tab[p.off_streams + strm], s_end = tab[p.off_streams + strm + 1];
+    if (s_begin >= s_end) return;
+    const AS4 i32x8* steps = (const AS4 i32x8*)(tab + p.off_steps);
+
     const int kvh = hslot % p.Hkv;
     const int hg = hslot / p.Hkv;
     const int hin = hg * 4 + wave;
@@ -214,83 +215,77 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
 
     const int r = lane & 31;  // query row inside the block (S^T / O^T column)
     const int h = lane >> 5;
-    const int row = rb * RB + r;
-    const int row_ld = min(row, L - 1);
 
     // ---- Q fragments: B operand of S^T = K Q^T; lane (r, h) holds Q[row][16 ks + 8 h .. +7].
     bf16x8 qf[8];
-    {
-        const unsigned short* qp = p.q + b * p.q_sb + hq * p.q_sh + (int64_t)row_ld * p.q_sl + 8 * h;
+    auto load_q = [&](int b, int rb, int L) {
+        const int row_ld = min(rb * RB + r, L - 1);
+        const unsigned short* qp = p.q + (int64_t)b * p.q_sb + (int64_t)hq * p.q_sh + (int64_t)row_ld * p.q_sl + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
-    }
+    };
 
     // ---- staging geometry: thread covers chunk (tid & 15) of rows (tid >> 4) + 16 i, i = 0..3.
     const int st_row = tid >> 4, st_ch = tid & 15;
     const int st_off = tile_off(st_row, st_ch);  // + 16 * 256 * i for the other rows (swizzle term unchanged)
-    const unsigned short* kbase = p.k + b * p.k_sb + kvh * p.k_sh + st_ch * 8;
-    const unsigned short* vbase = p.v + b * p.v_sb + kvh * p.v_sh + st_ch * 8;
     u32x4 kreg[4], vreg[4];
-
-    // Byte offsets of this thread's four rows inside a tile; a tile's base address is wave-uniform, so the loads
-    // need no per-lane 64-bit arithmetic.  Only the last tile of a sequence can run past L and clamps its rows.
-    unsigned koff[4], voff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        koff[i] = (unsigned)((st_row + 16 * i) * p.k_sl * 2);
-        voff[i] = (unsigned)((st_row + 16 * i) * p.v_sl * 2);
-    }
-    auto stage_load = [&](int kt) {
-        const char* kt_base = reinterpret_cast<const char*>(kbase + (int64_t)kt * KT * p.k_sl);
-        const char* vt_base = reinterpret_cast<const char*>(vbase + (int64_t)kt * KT * p.v_sl);
-        if (kt * KT + KT <= L) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                kreg[i] = *reinterpret_cast<const u32x4*>(kt_base + koff[i]);
-                vreg[i] = *reinterpret_cast<const u32x4*>(vt_base + voff[i]);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int kr = min(kt * KT + st_row + 16 * i, L - 1);
-                kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)kr * p.k_sl);
-                vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)kr * p.v_sl);
-            }
-        }
+    // Next-tile rows travel global -> registers -> LDS.  The loads are buffer loads whose descriptor starts at the
+    // tile and ends with the sequence's last row, so rows past L read as zeros and no lane needs its own clamp; the
+    // per-lane offset (row inside the tile, 16-byte chunk) is the same for every tile.
+    const unsigned koff0 = (unsigned)st_row * (unsigned)p.k_sl * 2u + (unsigned)st_ch * 16u;
+    const unsigned voff0 = (unsigned)st_row * (unsigned)p.v_sl * 2u + (unsigned)st_ch * 16u;
+    const unsigned kstep = 16u * (unsigned)p.k_sl * 2u, vstep = 16u * (unsigned)p.v_sl * 2u;
+    auto tile_rsrc = [&](const unsigned short* base, int sb, int sh, int sl, int b, int kt, int L) {
+        const int64_t head = (int64_t)b * sb + (int64_t)kvh * sh;          // elements
+        const int64_t tile = (int64_t)kt * KT * sl;                        // elements from the head slice
+        const int64_t bytes = (((int64_t)L - 1) * sl + D - tile) * 2;      // from the tile to the end of row L - 1
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(base + head + tile), 0, (int)bytes, 0x00020000);
     };
+#define SDAG_STAGE_LOADS(B_, KT_, L_)                                                                         \
+    {                                                                                                         \
+        const auto krs = tile_rsrc(p.k, p.k_sb, p.k_sh, p.k_sl, (B_), (KT_), (L_));                           \
+        const auto vrs = tile_rsrc(p.v, p.v_sb, p.v_sh, p.v_sl, (B_), (KT_), (L_));                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+            kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, koff0 + i * kstep, 0, 0)); \
+            vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff0 + i * vstep, 0, 0)); \
+        }                                                                                                     \
+    }
     // V goes to LDS as fp16: P V then runs on the f16 MFMA with 11-bit probabilities instead of 8-bit ones.
     // bf16 -> fp16 is exact for 2^-14 <= |v| < 2^16; round-toward-zero conversion saturates larger values
     // instead of producing infinities, and a tag tells the consumers to redo such a tile with a scale.
-    auto stage_store = [&](int buf, unsigned seq) {
-        unsigned char* kd = smem + buf * TILE_BYTES + st_off;
-        unsigned char* vd = smem + (2 + buf) * TILE_BYTES + st_off;
-        float vmax = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<u32x4*>(kd + i * 16 * 256) = kreg[i];
-            u32x4 hv;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned w = vreg[i][j];
-                const float f0 = __uint_as_float(w << 16), f1 = __uint_as_float(w & 0xffff0000u);
-                vmax = max3_abs(vmax, f0, f1);
-                hv[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(f0, f1));
-            }
-            *reinterpret_cast<u32x4*>(vd + i * 16 * 256) = hv;
-        }
-        // exponent field >= 143 means |v| >= 2^16, beyond fp16
+    float vmax = 0.f;
+#define SDAG_STAGE_STORE(BUF_)                                                                                \
+    {                                                                                                         \
+        unsigned char* kd = smem + (BUF_) * TILE_BYTES + st_off;                                              \
+        unsigned char* vd = smem + (2 + (BUF_)) * TILE_BYTES + st_off;                                        \
+        vmax = 0.f;                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+            *reinterpret_cast<u32x4*>(kd + i * 16 * 256) = kreg[i];                                           \
+            u32x4 hv;                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                   \
+                const unsigned w = vreg[i][j];                                                                \
+                const float f0 = __uint_as_float(w << 16), f1 = __uint_as_float(w & 0xffff0000u);            \
+                vmax = max3_abs(vmax, f0, f1);                                                                \
+                hv[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(f0, f1));                     \
+            }                                                                                                 \
+            *reinterpret_cast<u32x4*>(vd + i * 16 * 256) = hv;                                                \
+        }                                                                                                     \
+    }
+    // exponent field >= 143 means |v| >= 2^16, beyond fp16
+    auto stage_tag = [&](int buf, unsigned seq) {
         const unsigned eb = (__float_as_uint(vmax) >> 23) & 0xffu;
         if (eb >= 143u) atomicMax(&vtag[buf], (seq << 8) | eb);
     };
     // Slow path for a V tile with values beyond the fp16 range: every thread reloads its part of the tile and
     // stores it scaled by 2^-e (the probabilities are scaled by 2^e to compensate).
-    auto restage_v_scaled = [&](int buf, int kt, int e) {
+    auto restage_v_scaled = [&](int buf, int b, int kt, int L, int e) {
         const float sc = __uint_as_float((unsigned)(127 - e) << 23);
         unsigned char* vd = smem + (2 + buf) * TILE_BYTES + st_off;
+        const char* vh = reinterpret_cast<const char*>(p.v + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int kr = min(kt * KT + st_row + 16 * i, L - 1);
-            const u32x4 raw = *reinterpret_cast<const u32x4*>(vbase + (int64_t)kr * p.v_sl);
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(vh + ((int64_t)kr * p.v_sl + st_ch * 8) * 2);
             u32x4 hv;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -317,64 +312,68 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
             v_off[db][hf] = (4 * h + vq) * 256 + (((((db ^ vq) << 2) | (cl ^ (2 * hf + h)))) << 4) + 8 * (vp & 1);
 
     f32x16 oacc[4];
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const float c = p.c;
 
-    // ---- software pipeline over the unit's items: the (tile, mask) pair of the NEXT tile is known one
-    // iteration ahead, so its K/V rows and mask words are requested before the current tile is computed, and
-    // the pair after that is fetched meanwhile.
-    int kt_cur = kt_first, mi_cur = mi_first;
-    int kt_nxt = 0, mi_nxt = -1;
-    if (it_begin + 1 < it_end) {
-        kt_nxt = items[(it_begin + 1) * 2];
-        mi_nxt = items[(it_begin + 1) * 2 + 1];
-    }
-    uint64_t mrow_cur = mi_cur >= 0 ? masks[(int64_t)mi_cur * RB + r] : ~0ull;
+    // ---- software pipeline over the stream's steps: the record of the NEXT step is known one iteration ahead,
+    // so its K/V rows are requested before the current tile is computed, and the record after that is fetched
+    // meanwhile.
+    i32x8 cur = steps[s_begin];
+    i32x8 nxt = steps[min(s_begin + 1, s_end - 1)];
+    load_q(cur[S_B] + bg, cur[S_RB], cur[S_L]);
     __syncthreads();  // vtag zeroed
-    stage_load(kt_cur);
-    stage_store(0, 1u);
+    SDAG_STAGE_LOADS(cur[S_B] + bg, cur[S_KT], cur[S_L]);
+    SDAG_STAGE_STORE(0);
+    stage_tag(0, 1u);
     __syncthreads();
 
 #ifdef SDAG_STAMPS
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
 #endif
-    int cur = 0;
-    for (int it = it_begin; it < it_end; ++it) {
-        const bool has_next = it + 1 < it_end;
-        const unsigned seq = (unsigned)(it - it_begin) + 1u;
-        uint64_t mrow_nxt = ~0ull;
-        if (has_next) {
-            if (mi_nxt >= 0) mrow_nxt = masks[(int64_t)mi_nxt * RB + r];
-#if !(SDAG_ABLATE & 1)
-            stage_load(kt_nxt);
-#endif
+    int bufc = 0;
+    unsigned seq = 1u;
+    for (int it = s_begin; it < s_end; ++it, ++seq) {
+        const bool has_next = it + 1 < s_end;
+        const i32x8 nn = steps[min(it + 2, s_end - 1)];
+        const int b_cur = cur[S_B] + bg, kt_cur = cur[S_KT], L_cur = cur[S_L];
+        const bool first = (cur[S_FLAGS] & 1) != 0, last = (cur[S_FLAGS] & 2) != 0;
+        if (first) {
+            m_run = -INFINITY;
+            l_run = 0.f;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
         }
-        // unconditional (index clamped to the unit's last item) so that no branch copies the loaded registers
-        const int it2 = min(it + 2, it_end - 1);
-        int kt_nn = items[it2 * 2], mi_nn = items[it2 * 2 + 1];
 
-        const unsigned char* kb_lds = smem + cur * TILE_BYTES;
-        const unsigned char* vb_lds = smem + (2 + cur) * TILE_BYTES;
+        const unsigned char* kb_lds = smem + bufc * TILE_BYTES;
+        const unsigned char* vb_lds = smem + (2 + bufc) * TILE_BYTES;
 
         STAMP(0);
-        // ---- S^T = K Q^T : two 32-key blocks.  The LDS reads run two k-steps ahead of the MFMAs that consume them.
-        // The mask enters as the initial accumulator: 0 where the pair is allowed, -inf where it is not (a finite
-        // product added to -inf stays -inf).  Accumulator register i of block kb is key 32 kb + (i & 3) + 8 (i >> 2)
-        // + 4 h.  These VALU operations overlap the LDS reads and MFMAs below instead of following them.
+        // ---- S^T = K Q^T : two 32-key blocks.  The mask enters as the initial accumulator: 0 where the pair is
+        // allowed, -inf where it is not (a finite product added to -inf stays -inf).  Accumulator register i of
+        // block kb is key 32 kb + (i & 3) + 8 (i >> 2) + 4 h; the tile's lane masks are stored in that order.
         f32x16 s0, s1;
-        if (mi_cur >= 0) {
-            const unsigned nlo = ~((unsigned)mrow_cur >> (4 * h));
-            const unsigned nhi = ~((unsigned)(mrow_cur >> 32) >> (4 * h));
+        const int moff = cur[S_MOFF];
+        if (moff) {
+            const AS4 u32x16* mp = (const AS4 u32x16*)(tab + moff);
+            {
+                const u32x16 ma = mp[0], mb = mp[1];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int bit = (i & 3) + 8 * (i >> 2);
-                s0[i] = __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)nlo, bit, 1) & 0xff800000u);
-                s1[i] = __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)nhi, bit, 1) & 0xff800000u);
+                for (int i = 0; i < 8; ++i) {
+                    s0[i] = mask_init(ma, i);
+                    s0[8 + i] = mask_init(mb, i);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // the second half reuses the first half's scalar registers
+            {
+                const u32x16 mc = mp[2], md = mp[3];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    s1[i] = mask_init(mc, i);
+                    s1[8 + i] = mask_init(md, i);
+                }
             }
         } else {
 #pragma unroll
@@ -394,30 +393,43 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
                 s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], s0, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[ks], qf[ks], s1, 0, 0, 0);
             }
+            // The next step's K/V rows are requested from inside the MFMA stream (a stream's last step requests
+            // its own tile again): a vector-memory instruction holds the wave's issue for about as long as three
+            // MFMAs run, which is free here and a stall anywhere else.
+#if !(SDAG_ABLATE & 1)
+            SDAG_STAGE_LOADS(nxt[S_B] + bg, nxt[S_KT], nxt[S_L]);
+#endif
             __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);  // 6 ds_read
 #pragma unroll
             for (int g = 0; g < 5; ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 ds_read
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 buffer load
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
         }
 #else
 #pragma unroll
         for (int i = 0; i < 16; ++i) { s0[i] += __builtin_bit_cast(float, (unsigned)qf[i & 7][0] << 16) ; s1[i] += (float)i; }
 #endif
-
         STAMP(1);
+        // The unit's last product is issued: its Q registers are free for the next unit's rows.
+        if (last && has_next) load_q(nxt[S_B] + bg, nxt[S_RB], nxt[S_L]);
+
         STAMP(2);
         // ---- V tile beyond the fp16 range? (rare; workgroup-uniform).  Checked here so that the LDS read of the
         // tag is covered by the QK^T MFMAs.
         int ve = 0;
         {
-            const unsigned tg = vtag[cur];
+            const unsigned tg = vtag[bufc];
             if ((tg >> 8) == seq) ve = min((int)(tg & 0xffu) - 142, 15);
         }
         if (ve > 0) {
-            restage_v_scaled(cur, kt_cur, ve);
+            restage_v_scaled(bufc, b_cur, kt_cur, L_cur, ve);
             __syncthreads();
         }
         // ---- online softmax (per query = per lane, halves combined by one exchange).  The running maximum is only
@@ -476,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         if (rescale) {
             l_run = l_run * alpha + rs;
             m_run = m_new;
-            if (it != it_begin) {  // O is still zero on the unit's first tile
+            if (!first) {  // O is still zero on a unit's first tile
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
 #pragma unroll
@@ -515,13 +527,24 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
                         u.hlf[1] = va[db][2 * kb + s][1];
                         oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(u.full, pf[kb][s], oacc[db], 0, 0, 0);
                     }
-            __builtin_amdgcn_sched_group_barrier(0x100, 12, 1);  // reads of block 0 and half of block 1
+            // The rows requested above are converted and written to the other tile buffer from inside this MFMA
+            // stream; nobody reads that buffer before the barrier below.
+#if !(SDAG_ABLATE & 1)
+            SDAG_STAGE_STORE(bufc ^ 1);
+#endif
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 1);  // reads of block 0
 #pragma unroll
-            for (int g = 0; g < 10; ++g) {
+            for (int g = 0; g < 12; ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 1);
+                if (g >= 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 1);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 1);
+            }
         }
 #else
 #pragma unroll
@@ -531,70 +554,87 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
 #endif
 
         STAMP(4);
-#if !(SDAG_ABLATE & 1)
-        if (has_next) stage_store(cur ^ 1, seq + 1u);
-#endif
+        stage_tag(bufc ^ 1, seq + 1u);
         STAMP(5);
         __syncthreads();
         STAMP(6);
-        cur ^= 1;
-        kt_cur = kt_nxt; mi_cur = mi_nxt; mrow_cur = mrow_nxt;
-        // The pair fetched above is consumed only now: keeping it opaque in vector registers until here stops
-        // the compiler from waiting for that load (and every load behind it) at the top of the iteration.
-        asm volatile("" : "+v"(kt_nn), "+v"(mi_nn));
-        kt_nxt = __builtin_amdgcn_readfirstlane(kt_nn);
-        mi_nxt = __builtin_amdgcn_readfirstlane(mi_nn);
+
+        // ---- end of a unit.  O^T register i of block db is column d = 32 db + (i & 3) + 8 (i >> 2) + 4 h of the
+        // lane's row.
+        if (last) {
+            const int rb = cur[S_RB];
+            const int slot = cur[S_SLOT];
+            const unsigned ubits = (unsigned)cur[S_UBITS];
+            if (slot >= 0) {
+                if (head_ok) {
+                    const int64_t gslot = (int64_t)slot + (int64_t)bg * p.slots_per_b;
+                    const int64_t prow = (gslot * p.Hq + hq) * RB + r;
+                    float* po = p.part_o + prow * D;
+#pragma unroll
+                    for (int db = 0; db < 4; ++db)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 w = {oacc[db][4 * g], oacc[db][4 * g + 1], oacc[db][4 * g + 2], oacc[db][4 * g + 3]};
+                            *reinterpret_cast<f32x4*>(po + 32 * db + 8 * g + 4 * h) = w;
+                        }
+                    if (h == 0) {
+                        p.part_ml[prow * 2] = m_run;
+                        p.part_ml[prow * 2 + 1] = l_run;
+                    }
+                }
+            } else if (p.out_f32) {
+                const int row = rb * RB + r;
+                if (head_ok && row < L_cur && !((ubits >> r) & 1u) && l_run > 0.f) {
+                    const float inv = 1.0f / l_run;
+                    float* op = reinterpret_cast<float*>(p.o) + (int64_t)b_cur * p.o_sb + (int64_t)row * p.o_sl + (int64_t)hq * p.o_sh;
+#pragma unroll
+                    for (int db = 0; db < 4; ++db)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 w = {oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv, oacc[db][4 * g + 2] * inv,
+                                       oacc[db][4 * g + 3] * inv};
+                            *reinterpret_cast<f32x4*>(op + 32 * db + 8 * g + 4 * h) = w;
+                        }
+                }
+            } else {
+                // bf16 output through LDS so that every store instruction writes whole 256-byte rows.  The tile
+                // buffer just consumed is free until the end of the next step; the barrier below keeps the other
+                // waves from staging into it while this wave still reads its rows back.
+                unsigned char* stg = smem + (wave < 2 ? bufc : 2 + bufc) * TILE_BYTES + (wave & 1) * (TILE_BYTES / 2);
+                const float inv = 1.0f / l_run;  // rows that allow nothing are not stored
+#pragma unroll
+                for (int db = 0; db < 4; ++db)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        bf16x4 w = {(__bf16)(oacc[db][4 * g] * inv), (__bf16)(oacc[db][4 * g + 1] * inv),
+                                    (__bf16)(oacc[db][4 * g + 2] * inv), (__bf16)(oacc[db][4 * g + 3] * inv)};
+                        *reinterpret_cast<bf16x4*>(stg + r * 256 + (((4 * db + g) ^ (r & 15)) << 4) + 8 * h) = w;
+                    }
+                const int ch = lane & 15;
+                unsigned short* ob = reinterpret_cast<unsigned short*>(p.o) + (int64_t)b_cur * p.o_sb + (int64_t)hq * p.o_sh + ch * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int rr = 4 * j + (lane >> 4);
+                    const u32x4 w = *reinterpret_cast<const u32x4*>(stg + rr * 256 + ((ch ^ (rr & 15)) << 4));
+                    const int row = rb * RB + rr;
+                    if (head_ok && row < L_cur && !((ubits >> rr) & 1u))
+                        *reinterpret_cast<u32x4*>(ob + (int64_t)row * p.o_sl) = w;
+                }
+                __syncthreads();
+            }
+        }
+        STAMP(7);
+        bufc ^= 1;
+        cur = nxt;
+        nxt = nn;
     }
 
 #ifdef SDAG_STAMPS
     if (blockIdx.x == 0 && tid == 0) {
-        for (int i = 0; i < 7; ++i) g_stamps[i] = st_acc[i];
-        g_stamps[7] = (unsigned long long)(it_end - it_begin);
+        for (int i = 0; i < 8; ++i) g_stamps[i] = st_acc[i];
+        g_stamps[15] = (unsigned long long)(s_end - s_begin);
     }
 #endif
-    if (!head_ok) return;
-
-    // ---- epilogue.  O^T register i of block db is column d = 32 db + (i & 3) + 8 (i >> 2) + 4 h of row `row`.
-    if (gslot >= 0) {
-        const int64_t prow = ((int64_t)gslot * p.Hq + hq) * RB + r;
-        float* po = p.part_o + prow * D;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 w = {oacc[db][4 * g], oacc[db][4 * g + 1], oacc[db][4 * g + 2], oacc[db][4 * g + 3]};
-                *reinterpret_cast<f32x4*>(po + 32 * db + 8 * g + 4 * h) = w;
-            }
-        if (h == 0) {
-            p.part_ml[prow * 2] = m_run;
-            p.part_ml[prow * 2 + 1] = l_run;
-        }
-        return;
-    }
-    if (row >= L || ((uniform_bits >> r) & 1u) || !(l_run > 0.f)) return;
-    const float inv = 1.0f / l_run;
-    const int64_t obase = b * p.o_sb + (int64_t)row * p.o_sl + hq * p.o_sh;
-    if (p.out_f32) {
-        float* op = reinterpret_cast<float*>(p.o) + obase;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 w = {oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv, oacc[db][4 * g + 2] * inv,
-                           oacc[db][4 * g + 3] * inv};
-                *reinterpret_cast<f32x4*>(op + 32 * db + 8 * g + 4 * h) = w;
-            }
-    } else {
-        unsigned short* op = reinterpret_cast<unsigned short*>(p.o) + obase;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 w = {(__bf16)(oacc[db][4 * g] * inv), (__bf16)(oacc[db][4 * g + 1] * inv),
-                            (__bf16)(oacc[db][4 * g + 2] * inv), (__bf16)(oacc[db][4 * g + 3] * inv)};
-                *reinterpret_cast<bf16x4*>(op + 32 * db + 8 * g + 4 * h) = w;
-            }
-    }
 }
 
 // Merge the partial results of split row blocks, and write mean(V) into rows that allow nothing.
@@ -652,7 +692,7 @@ __global__ __launch_bounds__(256) void sdag_attn_combine(const AttnParams p, int
             }
         }
         const float inv = 1.0f / den;
-        const int64_t obase = b * p.o_sb + (int64_t)row * p.o_sl + hq * p.o_sh + c0;
+        const int64_t obase = (int64_t)b * p.o_sb + (int64_t)row * p.o_sl + (int64_t)hq * p.o_sh + c0;
         if (p.out_f32) {
             float* op = reinterpret_cast<float*>(p.o) + obase;
 #pragma unroll
@@ -700,7 +740,7 @@ __global__ __launch_bounds__(256) void sdag_attn_combine(const AttnParams p, int
         t += x;
     }
     const float invL = 1.0f / (float)L;
-    const int64_t obase = b * p.o_sb + (int64_t)row * p.o_sl + hq * p.o_sh + c0;
+    const int64_t obase = (int64_t)b * p.o_sb + (int64_t)row * p.o_sl + (int64_t)hq * p.o_sh + c0;
     if (p.out_f32) {
         f32x4 w = {t[0] * invL, t[1] * invL, t[2] * invL, t[3] * invL};
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.o) + obase) = w;
@@ -764,7 +804,7 @@ int check_common(const Tensors& t, int B, int Hq, int Hkv, int L, int Dh, float 
     if (!t.q || !t.k || !t.v || !t.o) return fail(SDAG_ERR_ARG, "NULL tensor pointer");
     const int64_t strides[] = {t.q_sb, t.q_sh, t.q_sl, t.k_sb, t.k_sh, t.k_sl, t.v_sb, t.v_sh, t.v_sl, t.o_sb, t.o_sl, t.o_sh};
     for (int64_t st : strides)
-        if (st < 0 || (st & 7)) return fail(SDAG_ERR_ARG, "strides must be non-negative multiples of 8 elements");
+        if (st < 0 || (st & 7) || st > 0x7fffffff) return fail(SDAG_ERR_ARG, "strides must be non-negative multiples of 8 elements below 2^31");
     if ((int64_t)L * t.k_sl * 2 >= (1ll << 32) || (int64_t)L * t.v_sl * 2 >= (1ll << 32))
         return fail(SDAG_ERR_ARG, "one (batch, head) slice of K or V must span less than 4 GiB");
     if (((uintptr_t)t.q | (uintptr_t)t.k | (uintptr_t)t.v | (uintptr_t)t.o) & 15) return fail(SDAG_ERR_ARG, "tensor pointers must be 16-byte aligned");
@@ -772,13 +812,13 @@ int check_common(const Tensors& t, int B, int Hq, int Hkv, int L, int Dh, float 
 }
 
 // Launch main (+ column-sum blocks) and, if anything needs it, the combine kernel.
-int launch(AttnParams& p, const Tensors& t, int B, int Hq, int Hkv, float scale, int out_dtype, int64_t n_pairs,
+int launch(AttnParams& p, const Tensors& t, int B, int Hq, int Hkv, float scale, int out_dtype, int64_t n_stream_blocks,
            int64_t n_slots_total, int64_t n_merge_entries, int64_t n_uniform_total, void* workspace, hipStream_t st) {
     p.q = (const unsigned short*)t.q; p.k = (const unsigned short*)t.k; p.v = (const unsigned short*)t.v; p.o = t.o;
-    p.q_sb = t.q_sb; p.q_sh = t.q_sh; p.q_sl = t.q_sl;
-    p.k_sb = t.k_sb; p.k_sh = t.k_sh; p.k_sl = t.k_sl;
-    p.v_sb = t.v_sb; p.v_sh = t.v_sh; p.v_sl = t.v_sl;
-    p.o_sb = t.o_sb; p.o_sl = t.o_sl; p.o_sh = t.o_sh;
+    p.q_sb = (int)t.q_sb; p.q_sh = (int)t.q_sh; p.q_sl = (int)t.q_sl;
+    p.k_sb = (int)t.k_sb; p.k_sh = (int)t.k_sh; p.k_sl = (int)t.k_sl;
+    p.v_sb = (int)t.v_sb; p.v_sh = (int)t.v_sh; p.v_sl = (int)t.v_sl;
+    p.o_sb = (int)t.o_sb; p.o_sl = (int)t.o_sl; p.o_sh = (int)t.o_sh;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv;
     p.G = Hq / Hkv;
     p.HG = (p.G + 3) / 4;
@@ -788,7 +828,7 @@ int launch(AttnParams& p, const Tensors& t, int B, int Hq, int Hkv, float scale,
     p.part_o = ws;
     p.part_ml = ws + n_slots_total * Hq * RB * D;
     p.vsum = p.part_ml + n_slots_total * Hq * RB * 2;
-    const int64_t main_blocks = n_pairs * Hkv * p.HG;
+    const int64_t main_blocks = n_stream_blocks * Hkv * p.HG;
     const int64_t vsum_blocks = n_uniform_total > 0 ? (int64_t)B * Hkv * VSUM_CHUNKS : 0;
     if (main_blocks + vsum_blocks > 0x7fffffff) return fail(SDAG_ERR_ARG, "grid too large");
     p.n_main_blocks = (int)main_blocks;
@@ -831,13 +871,13 @@ extern "C" int sdag_attn_fwd(const void* q, const void* k, const void* v, void* 
     AttnParams p;
     p.desc = desc_dev;
     p.btab = nullptr;
-    p.n_units = desc_host[H_NUNITS];
+    p.tab = desc_dev;
+    p.n_streams = desc_host[H_NSTREAMS];
+    p.off_streams = desc_host[H_OFF_STREAMS];
+    p.off_steps = desc_host[H_OFF_STEPS];
     p.n_slots = desc_host[H_NSLOTS];
-    p.L = L;
-    p.off_units = desc_host[H_OFF_UNITS];
-    p.off_items = desc_host[H_OFF_ITEMS];
-    p.off_masks = desc_host[H_OFF_MASKS];
-    return launch(p, t, B, Hq, Hkv, scale, out_dtype, (int64_t)p.n_units * B, (int64_t)p.n_slots * B,
+    p.slots_per_b = p.n_slots;
+    return launch(p, t, B, Hq, Hkv, scale, out_dtype, desc_host[H_NSTEPS] ? (int64_t)p.n_streams * B : 0, (int64_t)p.n_slots * B,
                   (int64_t)desc_host[H_NSPLIT] * B, (int64_t)desc_host[H_NUNIFORM] * B, workspace, (hipStream_t)stream);
 }
 
@@ -865,12 +905,13 @@ extern "C" int sdag_attn_fwd_batch(const void* q, const void* k, const void* v, 
     AttnParams p;
     p.desc = nullptr;
     p.btab = batch_dev;
-    p.n_units = 0;
+    p.tab = batch_dev;
+    p.n_streams = batch_host[BT_NSTREAMS];
+    p.off_streams = batch_host[BT_OFF_STREAMS];
+    p.off_steps = batch_host[BT_OFF_STEPS];
     p.n_slots = 0;
-    p.L = 0;
-    p.off_units = batch_host[BT_OFF_PAIRS];
-    p.off_items = p.off_masks = 0;
-    return launch(p, t, B, Hq, Hkv, scale, out_dtype, batch_host[BT_NPAIRS], batch_host[BT_NSLOTS], batch_host[BT_NMERGE],
+    p.slots_per_b = 0;
+    return launch(p, t, B, Hq, Hkv, scale, out_dtype, batch_host[BT_NSTEPS] ? batch_host[BT_NSTREAMS] : 0, batch_host[BT_NSLOTS], batch_host[BT_NMERGE],
                   batch_host[BT_NUNIFORM], workspace, (hipStream_t)stream);
 }
 

@@ -38,10 +38,69 @@ inline void set_range(uint64_t* row_bits, int a, int b) {  // columns [a, b), b 
     }
 }
 
+// One unit as the scheduler sees it.
+struct SchedUnit {
+    int32_t b, rb, item_begin, item_end, slot, ubits, L;
+    const int32_t* items;  // the sequence's {key tile, mask index} pairs
+    int64_t lmask_base;    // word offset (from the start of the table the steps live in) of that sequence's lane masks
+};
+
+// Deal the units, in the order given, to n_streams streams: each goes to the stream with the least work so far
+// (cost = key tiles + a fixed charge per unit for loading Q and storing O).  Writes the stream offsets (in steps)
+// and the step records.
+void build_schedule(const std::vector<SchedUnit>& units, int n_streams, int32_t* stream_off, int32_t* steps) {
+    std::vector<int64_t> load((size_t)n_streams, 0);
+    std::vector<std::vector<int32_t>> mine((size_t)n_streams);
+    for (size_t u = 0; u < units.size(); ++u) {
+        int best = 0;
+        for (int s = 1; s < n_streams; ++s)
+            if (load[s] < load[best]) best = s;
+        mine[best].push_back((int32_t)u);
+        load[best] += (units[u].item_end - units[u].item_begin) + 2;
+    }
+    int64_t n = 0;
+    for (int s = 0; s < n_streams; ++s) {
+        stream_off[s] = (int32_t)n;
+        for (int32_t ui : mine[s]) {
+            const SchedUnit& u = units[ui];
+            for (int it = u.item_begin; it < u.item_end; ++it, ++n) {
+                int32_t* w = steps + n * STEP_WORDS;
+                const int32_t mi = u.items[2 * it + 1];
+                w[S_KT] = u.items[2 * it];
+                w[S_MOFF] = mi < 0 ? 0 : (int32_t)(u.lmask_base + (int64_t)mi * 64);
+                w[S_FLAGS] = (it == u.item_begin ? 1 : 0) | (it + 1 == u.item_end ? 2 : 0);
+                w[S_B] = u.b;
+                w[S_L] = u.L;
+                w[S_RB] = u.rb;
+                w[S_SLOT] = u.slot;
+                w[S_UBITS] = u.ubits;
+            }
+        }
+    }
+    stream_off[n_streams] = (int32_t)n;
+}
+
+// 32 rows x 64 bits regrouped per accumulator register of the attention kernel (see common.h).
+void lane_mask_image(const uint64_t* rows, uint64_t* out) {
+    for (int kb = 0; kb < 2; ++kb)
+        for (int i = 0; i < 16; ++i) {
+            uint64_t w = 0;
+            for (int h = 0; h < 2; ++h) {
+                const int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                for (int r = 0; r < 32; ++r) w |= ((rows[r] >> key) & 1ull) << (r + 32 * h);
+            }
+            out[16 * kb + i] = w;
+        }
+}
+
+inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
 // fill(rb, bits): bits is RB * nkt words, zeroed by the caller; bits[r * nkt + t].
 using FillFn = std::function<void(int, uint64_t*)>;
 
-int emit(int L, const FillFn& fill, int max_items_per_unit, int32_t* out, int64_t cap_words, int64_t* n_words) {
+int emit(int L, const FillFn& fill, int max_items_per_unit, int n_streams, int32_t* out, int64_t cap_words, int64_t* n_words) {
+    if (n_streams <= 0) n_streams = DEFAULT_STREAMS;
+    if (n_streams > 65536) return fail(SDAG_ERR_ARG, "too many streams");
     const int nrb = (L + RB - 1) / RB;
     const int nkt = (L + KT - 1) / KT;
     std::vector<uint64_t> bits((size_t)RB * std::max(nkt, 1));
@@ -126,12 +185,17 @@ int emit(int L, const FillFn& fill, int max_items_per_unit, int32_t* out, int64_
     const int64_t off_rbinfo = off; off += (int64_t)nrb * 2;
     const int64_t off_split = off;  off += (int64_t)split.size();
     const int64_t off_uniform = off; off += (int64_t)uniform.size();
-    const int64_t total = off;
+    off = align_up(off, 16);
+    const int64_t off_lmasks = off; off += (int64_t)masks.size() * 2;
+    const int64_t off_streams = off; off += n_streams + 1;
+    off = align_up(off, 8);
+    const int64_t off_steps = off;  off += (int64_t)n_items * STEP_WORDS;
+    const int64_t total = align_up(off, 16);
     if (n_words) *n_words = total;
     if (total > 0x7fffffff) return fail(SDAG_ERR_ARG, "descriptor too large (%lld words)", (long long)total);
     if (!out || cap_words < total) return fail(SDAG_ERR_CAPACITY, "descriptor needs %lld words, buffer has %lld", (long long)total, (long long)cap_words);
 
-    std::memset(out, 0, sizeof(int32_t) * H_WORDS);
+    std::memset(out, 0, sizeof(int32_t) * (size_t)total);
     out[H_MAGIC] = DESC_MAGIC;
     out[H_VERSION] = DESC_VERSION;
     out[H_L] = L;
@@ -152,6 +216,11 @@ int emit(int L, const FillFn& fill, int max_items_per_unit, int32_t* out, int64_
     out[H_NSLOTS] = n_slots;
     out[H_PAIRS_LO] = (int32_t)(uint32_t)(pairs & 0xffffffffll);
     out[H_PAIRS_HI] = (int32_t)(uint32_t)((uint64_t)pairs >> 32);
+    out[H_NSTREAMS] = n_streams;
+    out[H_NSTEPS] = n_items;
+    out[H_OFF_LMASKS] = (int32_t)off_lmasks;
+    out[H_OFF_STREAMS] = (int32_t)off_streams;
+    out[H_OFF_STEPS] = (int32_t)off_steps;
     for (size_t u = 0; u < units.size(); ++u) {
         int32_t* p = out + off_units + u * UNIT_WORDS;
         p[0] = units[u].rb; p[1] = units[u].b; p[2] = units[u].e; p[3] = units[u].slot;
@@ -166,6 +235,13 @@ int emit(int L, const FillFn& fill, int max_items_per_unit, int32_t* out, int64_
     if (nrb) std::memcpy(out + off_rbinfo, rbinfo.data(), sizeof(int32_t) * rbinfo.size());
     if (!split.empty()) std::memcpy(out + off_split, split.data(), sizeof(int32_t) * split.size());
     if (!uniform.empty()) std::memcpy(out + off_uniform, uniform.data(), sizeof(int32_t) * uniform.size());
+    for (size_t m = 0; m < masks.size() / RB; ++m)
+        lane_mask_image(masks.data() + m * RB, reinterpret_cast<uint64_t*>(out + off_lmasks) + m * 32);
+    std::vector<SchedUnit> su;
+    su.reserve(units.size());
+    for (const Unit& u : units)
+        su.push_back({0, u.rb, u.b, u.e, u.slot, rbinfo[(size_t)u.rb * 2], L, items.data(), off_lmasks});
+    build_schedule(su, n_streams, out + off_streams, out + off_steps);
     return SDAG_OK;
 }
 
@@ -179,7 +255,7 @@ extern "C" const char* sdag_last_error(void) { return err_buf(); }
 
 extern "C" int sdag_desc_build(int L, int sys_user_len, int n_docs, const int32_t* spans, int qa_start,
                                const int32_t* nbr_off, const int32_t* nbr_idx, int max_items_per_unit,
-                               int32_t* out, int64_t cap_words, int64_t* n_words) {
+                               int n_streams, int32_t* out, int64_t cap_words, int64_t* n_words) {
     if (L < 0 || n_docs < 0) return fail(SDAG_ERR_ARG, "negative L or n_docs");
     if (sys_user_len < 0 || sys_user_len > L) return fail(SDAG_ERR_ARG, "sys_user_len %d outside [0, %d]", sys_user_len, L);
     if (qa_start < 0) return fail(SDAG_ERR_ARG, "qa_start negative");
@@ -216,10 +292,10 @@ extern "C" int sdag_desc_build(int L, int sys_user_len, int n_docs, const int32_
             }
         }
     };
-    return emit(L, fill, max_items_per_unit, out, cap_words, n_words);
+    return emit(L, fill, max_items_per_unit, n_streams, out, cap_words, n_words);
 }
 
-extern "C" int sdag_desc_from_dense(const uint8_t* mask, int L, int max_items_per_unit, int32_t* out,
+extern "C" int sdag_desc_from_dense(const uint8_t* mask, int L, int max_items_per_unit, int n_streams, int32_t* out,
                                     int64_t cap_words, int64_t* n_words) {
     if (L < 0 || (L > 0 && !mask)) return fail(SDAG_ERR_ARG, "bad dense mask");
     const int nkt = (L + SDAG_KV_TILE - 1) / SDAG_KV_TILE;
@@ -232,7 +308,7 @@ extern "C" int sdag_desc_from_dense(const uint8_t* mask, int L, int max_items_pe
                 if (src[j]) row[j >> 6] |= 1ull << (j & 63);
         }
     };
-    return emit(L, fill, max_items_per_unit, out, cap_words, n_words);
+    return emit(L, fill, max_items_per_unit, n_streams, out, cap_words, n_words);
 }
 
 extern "C" int sdag_desc_stats(const int32_t* d, int64_t* allowed_pairs, int32_t* n_uniform_rows,
@@ -246,42 +322,44 @@ extern "C" int sdag_desc_stats(const int32_t* d, int64_t* allowed_pairs, int32_t
     return SDAG_OK;
 }
 
-extern "C" int sdag_batch_build(const int32_t* const* descs, int B, int32_t* out, int64_t cap_words, int64_t* n_words) {
+extern "C" int sdag_batch_build(const int32_t* const* descs, int B, int n_streams, int32_t* out, int64_t cap_words,
+                                int64_t* n_words) {
     if (B <= 0 || !descs) return fail(SDAG_ERR_ARG, "bad batch");
+    if (n_streams <= 0) n_streams = DEFAULT_STREAMS;
+    if (n_streams > 65536) return fail(SDAG_ERR_ARG, "too many streams");
     for (int b = 0; b < B; ++b)
         if (!desc_ok(descs[b])) return fail(SDAG_ERR_DESC, "sequence %d: not a descriptor", b);
-    struct Pair { int32_t b, unit, len; };
-    std::vector<Pair> pairs;
     std::vector<int32_t> merge, uniform, slot_base(B), desc_off(B);
-    int64_t n_slots = 0;
+    int64_t n_slots = 0, n_units = 0, n_steps = 0;
     int lmax = 0;
     for (int b = 0; b < B; ++b) {
         const int32_t* d = descs[b];
         lmax = std::max(lmax, d[H_L]);
         slot_base[b] = (int32_t)n_slots;
         n_slots += d[H_NSLOTS];
-        const int32_t* u = d + d[H_OFF_UNITS];
-        for (int i = 0; i < d[H_NUNITS]; ++i) pairs.push_back({b, i, u[UNIT_WORDS * i + 2] - u[UNIT_WORDS * i + 1]});
+        n_units += d[H_NUNITS];
+        n_steps += d[H_NITEMS];
         for (int e = 0; e < d[H_NSPLIT]; ++e) { merge.push_back(b); merge.push_back(e); }
         const int32_t* un = d + d[H_OFF_UNIFORM];
         for (int i = 0; i < d[H_NUNIFORM]; ++i) { uniform.push_back(b); uniform.push_back(un[i]); }
     }
-    // Sequence-major order (units inside a descriptor are already longest first): the blocks that read one
-    // sequence's K/V run together, so those rows stay in the XCD's L2 while they are needed.
     int64_t off = BT_WORDS;
     const int64_t off_desc = off;     off += B;
     const int64_t off_slot = off;     off += B;
-    const int64_t off_pairs = off;    off += (int64_t)pairs.size() * PAIR_WORDS;
     const int64_t off_merge = off;    off += (int64_t)merge.size();
     const int64_t off_uniform = off;  off += (int64_t)uniform.size();
-    // descriptors: one copy per distinct pointer, each at an even word offset (their masks are 64-bit words)
+    const int64_t off_streams = off;  off += n_streams + 1;
+    off = align_up(off, 8);
+    const int64_t off_steps = off;    off += n_steps * STEP_WORDS;
+    // descriptors: one copy per distinct pointer, each at a multiple of 16 words (their lane masks are read in
+    // 64-byte pieces)
     std::vector<const int32_t*> uniq;
     for (int b = 0; b < B; ++b) {
         size_t j = 0;
         while (j < uniq.size() && uniq[j] != descs[b]) ++j;
         if (j == uniq.size()) {
             uniq.push_back(descs[b]);
-            if (off & 1) ++off;
+            off = align_up(off, 16);
             desc_off[b] = (int32_t)off;
             off += descs[b][H_TOTAL_WORDS];
         } else {
@@ -289,48 +367,46 @@ extern "C" int sdag_batch_build(const int32_t* const* descs, int B, int32_t* out
                 if (descs[c] == descs[b]) { desc_off[b] = desc_off[c]; break; }
         }
     }
-    const int64_t total = off;
+    const int64_t total = align_up(off, 16);
     if (n_words) *n_words = total;
     if (total > 0x7fffffff || n_slots > 0x7fffffff) return fail(SDAG_ERR_ARG, "batch table too large");
     if (!out || cap_words < total) return fail(SDAG_ERR_CAPACITY, "batch table needs %lld words, buffer has %lld", (long long)total, (long long)cap_words);
     std::memset(out, 0, sizeof(int32_t) * (size_t)total);
     out[BT_MAGIC] = BATCH_MAGIC;
-    out[BT_VERSION] = 1;
+    out[BT_VERSION] = BATCH_VERSION;
     out[BT_B] = B;
-    out[BT_NPAIRS] = (int32_t)pairs.size();
+    out[BT_NPAIRS] = (int32_t)n_units;
     out[BT_NMERGE] = (int32_t)(merge.size() / 2);
     out[BT_NUNIFORM] = (int32_t)(uniform.size() / 2);
     out[BT_NSLOTS] = (int32_t)n_slots;
     out[BT_OFF_DESC] = (int32_t)off_desc;
     out[BT_OFF_SLOTBASE] = (int32_t)off_slot;
-    out[BT_OFF_PAIRS] = (int32_t)off_pairs;
     out[BT_OFF_MERGE] = (int32_t)off_merge;
     out[BT_OFF_UNIFORM] = (int32_t)off_uniform;
     out[BT_TOTAL_WORDS] = (int32_t)total;
     out[BT_LMAX] = lmax;
+    out[BT_NSTREAMS] = n_streams;
+    out[BT_NSTEPS] = (int32_t)n_steps;
+    out[BT_OFF_STREAMS] = (int32_t)off_streams;
+    out[BT_OFF_STEPS] = (int32_t)off_steps;
     for (int b = 0; b < B; ++b) {
         out[off_desc + b] = desc_off[b];
         out[off_slot + b] = slot_base[b];
     }
-    for (size_t i = 0; i < pairs.size(); ++i) {
-        const int b = pairs[i].b;
-        const int32_t* dsc = descs[b];
-        const int32_t* u = dsc + dsc[H_OFF_UNITS] + (size_t)pairs[i].unit * UNIT_WORDS;
-        int32_t* r = out + off_pairs + i * PAIR_WORDS;
-        r[0] = b;
-        r[1] = u[0];
-        r[2] = u[1];
-        r[3] = u[2];
-        r[4] = u[3] < 0 ? -1 : slot_base[b] + u[3];
-        r[5] = u[4];
-        r[6] = dsc[H_L];
-        r[7] = u[5];
-        r[8] = u[6];
-        r[9] = desc_off[b] + dsc[H_OFF_ITEMS];
-        r[10] = desc_off[b] + dsc[H_OFF_MASKS];
-    }
     if (!merge.empty()) std::memcpy(out + off_merge, merge.data(), sizeof(int32_t) * merge.size());
     if (!uniform.empty()) std::memcpy(out + off_uniform, uniform.data(), sizeof(int32_t) * uniform.size());
     for (int b = 0; b < B; ++b) std::memcpy(out + desc_off[b], descs[b], sizeof(int32_t) * (size_t)descs[b][H_TOTAL_WORDS]);
+    // Sequence-major order (units inside a descriptor are already longest first): the workgroups that read one
+    // sequence's K/V run together, so those rows stay in the XCD's L2 while they are needed.
+    std::vector<SchedUnit> su;
+    su.reserve((size_t)n_units);
+    for (int b = 0; b < B; ++b) {
+        const int32_t* d = descs[b];
+        const int32_t* u = d + d[H_OFF_UNITS];
+        for (int i = 0; i < d[H_NUNITS]; ++i, u += UNIT_WORDS)
+            su.push_back({b, u[0], u[1], u[2], u[3] < 0 ? -1 : slot_base[b] + u[3], u[4], d[H_L], d + d[H_OFF_ITEMS],
+                          (int64_t)desc_off[b] + d[H_OFF_LMASKS]});
+    }
+    build_schedule(su, n_streams, out + off_streams, out + off_steps);
     return SDAG_OK;
 }

@@ -34,13 +34,13 @@ i64 = ctypes.c_int64
 SIGNATURES = {
     "sdag_version": (i32, []),
     "sdag_last_error": (ctypes.c_char_p, []),
-    "sdag_desc_build": (i32, [i32, i32, i32, vp, i32, vp, vp, i32, vp, i64, c_i64p]),
-    "sdag_desc_from_dense": (i32, [vp, i32, i32, vp, i64, c_i64p]),
+    "sdag_desc_build": (i32, [i32, i32, i32, vp, i32, vp, vp, i32, i32, vp, i64, c_i64p]),
+    "sdag_desc_from_dense": (i32, [vp, i32, i32, i32, vp, i64, c_i64p]),
     "sdag_desc_stats": (i32, [vp, c_i64p, c_i32p, c_i32p, c_i32p, c_i32p]),
     "sdag_mask_materialize": (i32, [vp, vp, vp, vp]),
     "sdag_attn_workspace_bytes": (i64, [vp, i32, i32, i32]),
     "sdag_attn_fwd": (i32, [vp, vp, vp, vp] + [i64] * 12 + [i32] * 5 + [ctypes.c_float, vp, vp, vp, i64, i32, vp]),
-    "sdag_batch_build": (i32, [vp, i32, vp, i64, c_i64p]),
+    "sdag_batch_build": (i32, [vp, i32, i32, vp, i64, c_i64p]),
     "sdag_attn_batch_workspace_bytes": (i64, [vp, i32, i32]),
     "sdag_attn_fwd_batch": (i32, [vp, vp, vp, vp] + [i64] * 12 + [i32] * 5 + [ctypes.c_float, vp, vp, vp, i64, i32, vp]),
     "sdag_dense_workspace_bytes": (i64, [i32, i64, i32, i32]),

@@ -18,6 +18,7 @@ from . import _lib
 
 H_L, H_NRB, H_NKT, H_NUNITS, H_NITEMS, H_NMASKS, H_NSPLIT, H_NUNIFORM = 2, 3, 4, 5, 6, 7, 8, 9
 H_NSLOTS = 17
+H_NSTREAMS = 20
 
 _scratch = np.empty(1 << 16, dtype=np.int32)
 
@@ -53,6 +54,10 @@ class Descriptor:
     @property
     def n_slots(self) -> int:
         return int(self.host[H_NSLOTS])
+
+    @property
+    def n_streams(self) -> int:
+        return int(self.host[H_NSTREAMS])
 
     @property
     def allowed_pairs(self) -> int:
@@ -109,11 +114,13 @@ def from_spans(
     qa_start: int,
     doc_neighbors: Optional[Sequence[Sequence[int]]] = None,
     max_items_per_unit: int = 0,
+    n_streams: int = 0,
 ) -> Descriptor:
     """Descriptor of the SDAG mask; argument meaning as in build_blocked_causal_mask_full (SDAG.py:68-76).
 
     ``doc_neighbors`` is ignored unless it has one entry per document (SDAG.py:111).  Values the reference
     would index out of range with (negative positions, spans past L) raise ``ValueError``.
+    ``n_streams`` is the number of work streams the units are dealt to (0 = 64, see ``streams_for``).
     """
     n_docs = len(doc_token_spans)
     spans = np.asarray([int(x) for se in doc_token_spans for x in se], dtype=np.int32).reshape(-1)
@@ -133,7 +140,7 @@ def from_spans(
         return lib.sdag_desc_build(int(base_seq_len), int(sys_user_len), n_docs, spans.ctypes.data if n_docs else None,
                                    int(qa_start), nbr_off.ctypes.data if use_nbr else None,
                                    nbr_idx.ctypes.data if use_nbr and nbr_idx.size else None,
-                                   int(max_items_per_unit), out_ptr, cap, need)
+                                   int(max_items_per_unit), int(n_streams), out_ptr, cap, need)
 
     try:
         return Descriptor(_run_builder(call))
@@ -143,7 +150,14 @@ def from_spans(
         raise
 
 
-def from_dense(mask, max_items_per_unit: int = 0) -> Descriptor:
+def streams_for(Hq: int, Hkv: int, compute_units: int = 256, batch: int = 1) -> int:
+    """Streams that fill ``compute_units`` at two workgroups each: one workgroup serves a stream for up to four
+    query heads that share a key/value head."""
+    slots = Hkv * ((Hq // Hkv + 3) // 4) * max(1, batch)
+    return max(1, -(-2 * compute_units // slots))
+
+
+def from_dense(mask, max_items_per_unit: int = 0, n_streams: int = 0) -> Descriptor:
     """Descriptor of an arbitrary boolean [L, L] mask (numpy or torch, any device)."""
     if isinstance(mask, torch.Tensor):
         mask = mask.detach().to("cpu").numpy()
@@ -153,7 +167,7 @@ def from_dense(mask, max_items_per_unit: int = 0) -> Descriptor:
     lib = _lib.lib()
 
     def call(out_ptr, cap, need):
-        return lib.sdag_desc_from_dense(m.ctypes.data, m.shape[0], int(max_items_per_unit), out_ptr, cap, need)
+        return lib.sdag_desc_from_dense(m.ctypes.data, m.shape[0], int(max_items_per_unit), int(n_streams), out_ptr, cap, need)
 
     return Descriptor(_run_builder(call))
 
@@ -161,7 +175,7 @@ def from_dense(mask, max_items_per_unit: int = 0) -> Descriptor:
 class BatchDescriptor:
     """Descriptors of several sequences packed for one launch (``sdag_attn_fwd_batch``)."""
 
-    def __init__(self, descs: Sequence[Descriptor]):
+    def __init__(self, descs: Sequence[Descriptor], n_streams: int = 0):
         if not descs:
             raise ValueError("empty batch")
         self.descs = list(descs)
@@ -169,7 +183,7 @@ class BatchDescriptor:
         lib = _lib.lib()
 
         def call(out_ptr, cap, need):
-            return lib.sdag_batch_build(ptrs, len(descs), out_ptr, cap, need)
+            return lib.sdag_batch_build(ptrs, len(descs), int(n_streams), out_ptr, cap, need)
 
         self.host = _run_builder(call)
         self._dev: Dict[torch.device, torch.Tensor] = {}

@@ -8,7 +8,8 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 H = dict(L=2, NRB=3, NKT=4, NUNITS=5, NITEMS=6, NMASKS=7, NSPLIT=8, NUNIFORM=9, OFF_UNITS=10, OFF_ITEMS=11,
-         OFF_MASKS=12, OFF_RBINFO=13, OFF_SPLIT=14, OFF_UNIFORM=15, TOTAL=16, NSLOTS=17)
+         OFF_MASKS=12, OFF_RBINFO=13, OFF_SPLIT=14, OFF_UNIFORM=15, TOTAL=16, NSLOTS=17, NSTREAMS=20, NSTEPS=21,
+         OFF_LMASKS=22, OFF_STREAMS=23, OFF_STEPS=24)
 
 
 def load_masks():
@@ -54,6 +55,58 @@ def expand_descriptor(words):
                 out[r0:r0 + rr, c0:c0 + cc] = bits[:rr, :cc]
     assert len(seen) == int(w[H["NITEMS"]])
     return out
+
+
+def lane_mask_to_rows(lm):
+    """Undo the per-accumulator-register regrouping of a 32 x 64 bit tile mask (32 uint64 in, 32 uint64 out)."""
+    rows = np.zeros(32, dtype=np.uint64)
+    for kb in range(2):
+        for i in range(16):
+            w = int(lm[16 * kb + i])
+            for h in range(2):
+                key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h
+                for r in range(32):
+                    if (w >> (r + 32 * h)) & 1:
+                        rows[r] |= np.uint64(1 << key)
+    return rows
+
+
+def check_schedule(words, steps_off, streams_off, n_streams, units_of, base_of=None):
+    """Walk the streams of a descriptor or batch table: every unit must appear exactly once, as a contiguous run
+    of steps that repeats its items in order.  units_of(b) -> (descriptor words, word offset of that descriptor in
+    the table); returns the per-stream step counts."""
+    w = np.asarray(words, dtype=np.int32)
+    so = w[streams_off: streams_off + n_streams + 1]
+    assert so[0] == 0 and (np.diff(so) >= 0).all()
+    steps = w[steps_off: steps_off + 8 * so[-1]].reshape(-1, 8)
+    seen = set()
+    for s in range(n_streams):
+        i = so[s]
+        while i < so[s + 1]:
+            kt, moff, flags, b, L, rb, slot, ubits = steps[i]
+            assert flags & 1
+            d, doff = units_of(int(b))
+            units = d[d[H["OFF_UNITS"]]: d[H["OFF_UNITS"]] + 8 * d[H["NUNITS"]]].reshape(-1, 8)
+            items = d[d[H["OFF_ITEMS"]]: d[H["OFF_ITEMS"]] + 2 * d[H["NITEMS"]]].reshape(-1, 2)
+            cand = [u for u in units if u[0] == rb and items[u[1]][0] == kt]
+            assert len(cand) == 1
+            u = cand[0]
+            key = (int(b), int(u[1]))
+            assert key not in seen
+            seen.add(key)
+            n = int(u[2] - u[1])
+            for j in range(n):
+                st = steps[i + j]
+                assert st[0] == items[u[1] + j][0] and st[3] == b and st[4] == d[H["L"]] and st[5] == rb
+                assert st[7] == u[4]
+                assert (st[2] & 1) == (j == 0) and bool(st[2] & 2) == (j == n - 1)
+                mi = items[u[1] + j][1]
+                if mi < 0:
+                    assert st[1] == 0
+                else:
+                    assert st[1] == doff + d[H["OFF_LMASKS"]] + 64 * mi and st[1] % 16 == 0
+            i += n
+    return seen, np.diff(so)
 
 
 def synthetic_layout(sys_len, doc_lens, gap, qa_len):

@@ -29,9 +29,9 @@ def test_error_reporting_without_gpu():
     lib = _lib.lib()
     assert lib.sdag_version() >= 1
     need = ctypes.c_int64(0)
-    rc = lib.sdag_desc_build(10, 20, 0, None, 0, None, None, 0, None, 0, ctypes.byref(need))
+    rc = lib.sdag_desc_build(10, 20, 0, None, 0, None, None, 0, 0, None, 0, ctypes.byref(need))
     assert rc == _lib.SDAG_ERR_ARG and b"sys_user_len" in lib.sdag_last_error()
-    rc = lib.sdag_desc_build(10, 2, 0, None, 5, None, None, 0, None, 0, ctypes.byref(need))
+    rc = lib.sdag_desc_build(10, 2, 0, None, 5, None, None, 0, 0, None, 0, ctypes.byref(need))
     assert rc == _lib.SDAG_ERR_CAPACITY and need.value > 32
     assert lib.sdag_dense_workspace_bytes(32, 1000, 64, 100) < 0   # k above the maximum
     assert lib.sdag_attn_workspace_bytes(None, 1, 4, 1) < 0

@@ -2,7 +2,8 @@
 import numpy as np
 import pytest
 
-from helpers import H, expand_descriptor, golden_bits, load_masks, mask_sha, synthetic_layout
+from helpers import (H, check_schedule, expand_descriptor, golden_bits, lane_mask_to_rows, load_masks, mask_sha,
+                     synthetic_layout)
 
 
 def test_descriptor_expands_to_reference_masks_bit_exact():
@@ -71,3 +72,48 @@ def test_invalid_arguments_raise():
         sdag_amd.from_spans(10, 2, [], -1)
     d = sdag_amd.from_spans(0, 0, [], 0)
     assert d.n_units == 0 and d.L == 0
+
+
+def test_streams_cover_every_unit_once_and_lane_masks_match():
+    import sdag_amd
+
+    K = 20
+    spans, qa, L = synthetic_layout(60, [380] * K, 1, 30)
+    nbr = [[(i + 1) % K, (i + 2) % K] for i in range(K)]
+    for n_streams, layout in ((0, (L, 60, spans, qa, nbr)), (7, (L, 60, spans, qa, None)), (3, (40, 5, [(6, 20)], 30, None))):
+        d = sdag_amd.from_spans(*layout, n_streams=n_streams)
+        w = d.host
+        ns = int(w[H["NSTREAMS"]])
+        assert ns == (n_streams or 64) and w[H["NSTEPS"]] == w[H["NITEMS"]]
+        assert w[H["OFF_LMASKS"]] % 16 == 0 and w[H["OFF_STEPS"]] % 8 == 0
+        seen, counts = check_schedule(w, int(w[H["OFF_STEPS"]]), int(w[H["OFF_STREAMS"]]), ns, lambda b: (w, 0))
+        assert len(seen) == w[H["NUNITS"]] and counts.sum() == w[H["NITEMS"]]
+        if w[H["NUNITS"]] >= ns:
+            units = w[w[H["OFF_UNITS"]]: w[H["OFF_UNITS"]] + 8 * w[H["NUNITS"]]].reshape(-1, 8)
+            longest = int((units[:, 2] - units[:, 1]).max())
+            assert counts.max() - counts.min() <= longest + 2       # greedy dealing keeps the streams level
+        masks = w[w[H["OFF_MASKS"]]: w[H["OFF_MASKS"]] + 64 * w[H["NMASKS"]]].view(np.uint64).reshape(-1, 32)
+        lmasks = w[w[H["OFF_LMASKS"]]: w[H["OFF_LMASKS"]] + 64 * w[H["NMASKS"]]].view(np.uint64).reshape(-1, 32)
+        for m in range(0, len(masks), max(1, len(masks) // 25)):
+            assert np.array_equal(lane_mask_to_rows(lmasks[m]), masks[m])
+
+
+def test_batch_table_streams():
+    import sdag_amd
+
+    a = sdag_amd.from_spans(*((lambda s, q, L: (L, 10, s, q))(*synthetic_layout(10, [70, 33], 2, 9))))
+    b = sdag_amd.from_spans(*((lambda s, q, L: (L, 4, s, q))(*synthetic_layout(4, [100] * 3, 1, 40))), max_items_per_unit=2)
+    bt = sdag_amd.BatchDescriptor([a, b, a], n_streams=5)
+    w = bt.host
+    B, ns = int(w[2]), int(w[14])
+    assert B == 3 and ns == 5
+    doff = w[w[7]: w[7] + B]
+    assert doff[0] == doff[2] != doff[1] and (doff % 16 == 0).all()
+    descs = [a, b, a]
+    seen, counts = check_schedule(w, int(w[17]), int(w[16]), ns, lambda i: (descs[i].host, int(doff[i])))
+    assert len(seen) == 2 * a.n_units + b.n_units and counts.sum() == w[15] == 2 * a.n_items + b.n_items
+    steps = w[w[17]: w[17] + 8 * w[15]].reshape(-1, 8)
+    slot_base = w[w[8]: w[8] + B]
+    gl = sorted(int(s[6]) for s in steps if (s[2] & 2) and s[6] >= 0)
+    assert gl == list(range(int(w[6])))                                # every global partial slot exactly once
+    assert list(slot_base) == [0, a.n_slots, a.n_slots + b.n_slots]

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(ROOT, "sparse-document-attention-rag-_amd")); sy
 import torch, sdag_amd
 from sdag_amd import _lib
 dev = torch.device("cuda:0")
-names = ["top(loads,vtag)", "QK^T", "mask", "softmax", "PV", "stage_store", "barrier"]
+names = ["top(loads,init)", "mask+QK^T", "Q load,vtag", "softmax", "PV", "stage_store", "barrier", "unit end"]
 def run(desc, L, label):
     q = torch.randn((1, L, 32, 128), device=dev).to(torch.bfloat16).transpose(1, 2)
     k = torch.randn((1, L, 8, 128), device=dev).to(torch.bfloat16).transpose(1, 2)
@@ -16,8 +16,8 @@ def run(desc, L, label):
         sdag_amd.sdag_attention(q, k, v, desc)
     out = (ctypes.c_ulonglong * 16)()
     _lib.check(_lib.lib().sdag_debug_stamps(out))
-    n = out[7]; tot = sum(out[i] for i in range(7))
-    print(f"{label}: {n} tiles, {tot / n:.0f} cycles/tile: " + ", ".join(f"{names[i]} {out[i] / n:.0f}" for i in range(7)), flush=True)
+    n = out[15]; tot = sum(out[i] for i in range(8))
+    print(f"{label}: {n} tiles, {tot / n:.0f} cycles/tile: " + ", ".join(f"{names[i]} {out[i] / n:.0f}" for i in range(8)), flush=True)
 L = 4096
 run(sdag_amd.from_spans(L, L, [], L, None, max_items_per_unit=100000), L, "causal4096 (chip full)")
 L = 2048
@@ -26,3 +26,4 @@ spans, pos = [], 60
 for _ in range(10):
     spans.append((pos, pos + 300)); pos += 301
 run(sdag_amd.from_spans(pos + 30, 60, spans, pos, None, max_items_per_unit=64), pos + 30, "cfg3 T=64 (QA unit)")
+run(sdag_amd.from_spans(pos + 30, 60, spans, pos, None), pos + 30, "cfg3 default units (stream 0)")
