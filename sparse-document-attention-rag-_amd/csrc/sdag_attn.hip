@@ -315,6 +315,31 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     float m_run = -INFINITY, l_run = 0.f;
     const float c = p.c;
 
+    // Initial S^T accumulators of a step from its lane-mask image (table offset MOFF_, 0 = every pair allowed).
+#define SDAG_INIT_SCORES(MOFF_)                                                                               \
+    {                                                                                                         \
+        const int moff_ = (MOFF_);                                                                            \
+        if (moff_) {                                                                                          \
+            const AS4 u32x16* mp = (const AS4 u32x16*)(tab + moff_);                                          \
+            {                                                                                                 \
+                const u32x16 ma = mp[0], mb = mp[1];                                                          \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                               \
+                    s0[i] = mask_init(ma, i);                                                                 \
+                    s0[8 + i] = mask_init(mb, i);                                                             \
+                }                                                                                             \
+            }                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0); /* the second half reuses the first half's scalar registers */ \
+            {                                                                                                 \
+                const u32x16 mc = mp[2], md = mp[3];                                                          \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                               \
+                    s1[i] = mask_init(mc, i);                                                                 \
+                    s1[8 + i] = mask_init(md, i);                                                             \
+                }                                                                                             \
+            }                                                                                                 \
+        } else {                                                                                              \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }                      \
+        }                                                                                                     \
+    }
     // ---- software pipeline over the stream's steps: the record of the NEXT step is known one iteration ahead,
     // so its K/V rows are requested before the current tile is computed, and the record after that is fetched
     // meanwhile.
@@ -325,6 +350,12 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     SDAG_STAGE_LOADS(cur[S_B] + bg, cur[S_KT], cur[S_L]);
     SDAG_STAGE_STORE(0);
     stage_tag(0, 1u);
+    // The mask enters as the initial accumulator: 0 where the pair is allowed, -inf where it is not (a finite
+    // product added to -inf stays -inf).  Accumulator register i of block kb is key 32 kb + (i & 3) + 8 (i >> 2)
+    // + 4 h; the tile's lane masks are stored in that order.  Each step prepares the accumulators of the next one
+    // once its own scores have been turned into probabilities.
+    f32x16 s0, s1;
+    SDAG_INIT_SCORES(cur[S_MOFF]);
     __syncthreads();
 
 #ifdef SDAG_STAMPS
@@ -351,34 +382,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         const unsigned char* vb_lds = smem + (2 + bufc) * TILE_BYTES;
 
         STAMP(0);
-        // ---- S^T = K Q^T : two 32-key blocks.  The mask enters as the initial accumulator: 0 where the pair is
-        // allowed, -inf where it is not (a finite product added to -inf stays -inf).  Accumulator register i of
-        // block kb is key 32 kb + (i & 3) + 8 (i >> 2) + 4 h; the tile's lane masks are stored in that order.
-        f32x16 s0, s1;
-        const int moff = cur[S_MOFF];
-        if (moff) {
-            const AS4 u32x16* mp = (const AS4 u32x16*)(tab + moff);
-            {
-                const u32x16 ma = mp[0], mb = mp[1];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    s0[i] = mask_init(ma, i);
-                    s0[8 + i] = mask_init(mb, i);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);  // the second half reuses the first half's scalar registers
-            {
-                const u32x16 mc = mp[2], md = mp[3];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    s1[i] = mask_init(mc, i);
-                    s1[8 + i] = mask_init(md, i);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
-        }
+        // ---- S^T = K Q^T : two 32-key blocks on top of the accumulators prepared from the mask.
 #if !(SDAG_ABLATE & 2)
         {
             bf16x8 ka[8], kb2[8];
@@ -419,6 +423,10 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         STAMP(1);
         // The unit's last product is issued: its Q registers are free for the next unit's rows.
         if (last && has_next) load_q(nxt[S_B] + bg, nxt[S_RB], nxt[S_L]);
+        // Touch the four 64-byte lines of the next step's lane mask now, so that the real loads further down
+        // find them in the scalar cache.
+        const int moff_n = nxt[S_MOFF];
+        const int touch0 = tab[moff_n], touch1 = tab[moff_n + 16], touch2 = tab[moff_n + 32], touch3 = tab[moff_n + 48];
 
         STAMP(2);
         // ---- V tile beyond the fp16 range? (rare; workgroup-uniform).  Checked here so that the LDS read of the
@@ -554,6 +562,8 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
 #endif
 
         STAMP(4);
+        asm volatile("" ::"s"(touch0), "s"(touch1), "s"(touch2), "s"(touch3));
+        SDAG_INIT_SCORES(moff_n);
         stage_tag(bufc ^ 1, seq + 1u);
         STAMP(5);
         __syncthreads();
