@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--corpus-n", type=int, default=CFG["corpus_n"])
     ap.add_argument("--mode", choices=("batched", "per_query"), default="batched")
     ap.add_argument("--no-probe", action="store_true", help="skip the extra B=1 calls timed after the run (for profiling)")
+    ap.add_argument("--attn-batch", type=int, default=CFG["batch"], help="queries per attention launch in batched mode (divides 32)")
     args = ap.parse_args()
     cfg = dict(CFG, corpus_n=args.corpus_n)
 
@@ -162,12 +163,17 @@ def main():
 
     batched = args.mode == "batched"
     nb = cfg["batch"]
+    ab = args.attn_batch
     if batched:
+        if nb % ab:
+            raise SystemExit("--attn-batch must divide the query batch")
         descs = [sdag_amd.from_spans(L, cfg["sys_len"], spans, qa, None, max_items_per_unit=64) for _ in range(nb)]
-        bdesc = sdag_amd.BatchDescriptor(descs)        # one descriptor per query, as different prompts would have
+        # one descriptor per query, as different prompts would have; ab queries share a launch
+        bdescs = [sdag_amd.BatchDescriptor(descs[i:i + ab]) for i in range(0, nb, ab)]
         sets = [make_set(nb, 1000 * rank + i) for i in range(4)]
-        bcalls = [sdag_amd.BoundBatchAttention(q_, k_, v_, bdesc, o_) for q_, k_, v_, o_ in sets]
-        layer_calls = [bcalls[i % len(bcalls)] for i in range(nl)]
+        bcalls = [[sdag_amd.BoundBatchAttention(q_[i:i + ab], k_[i:i + ab], v_[i:i + ab], bdescs[i // ab], o_[i:i + ab])
+                   for i in range(0, nb, ab)] for q_, k_, v_, o_ in sets]
+        layer_calls = [c for i in range(nl) for c in bcalls[i % len(bcalls)]]
         pq_sets = [tuple(t[:1] for t in sets[i]) for i in range(4)]
     else:
         pq_sets = [make_set(1, 1000 * rank + i) for i in range(nl)]
@@ -219,8 +225,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    n_launches = args.steps * nl * (1 if batched else cfg["batch"])
-    q_per_launch = cfg["batch"] if batched else 1
+    n_launches = args.steps * nl * (nb // ab if batched else cfg["batch"])
+    q_per_launch = ab if batched else 1
     t_sdag = sum(a.elapsed_time(b) for a, b in sdag_ms) * 1e-3
     t_retr = sum(a.elapsed_time(b) for a, b in retr_ms) * 1e-3
     per_launch = t_sdag / n_launches
