@@ -426,7 +426,8 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         // Touch the four 64-byte lines of the next step's lane mask now, so that the real loads further down
         // find them in the scalar cache.
         const int moff_n = nxt[S_MOFF];
-        const int touch0 = tab[moff_n], touch1 = tab[moff_n + 16], touch2 = tab[moff_n + 32], touch3 = tab[moff_n + 48];
+        const int tstep = moff_n ? 16 : 0;  // no mask: touch the table's first word only
+        const int touch0 = tab[moff_n], touch1 = tab[moff_n + tstep], touch2 = tab[moff_n + 2 * tstep], touch3 = tab[moff_n + 3 * tstep];
 
         STAMP(2);
         // ---- V tile beyond the fp16 range? (rare; workgroup-uniform).  Checked here so that the LDS read of the

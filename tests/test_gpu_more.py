@@ -316,3 +316,38 @@ def test_attention_batch_of_different_prompts():
     single = sdag_amd.sdag_attention(q[:3, :, :L].contiguous().to(DEV), k[:3, :, :L].contiguous().to(DEV),
                                      v[:3, :, :L].contiguous().to(DEV), descs[2], out_dtype=torch.float32).cpu()
     assert torch.equal(o2[:, :L], single)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_attention_random_layouts_streams_and_bf16_rows(seed):
+    """Random ragged layouts (empty documents, out-of-range neighbour ids, overlapping spans), random stream
+    counts and unit lengths: fp32 output against the oracle, bf16 output equal to its rounding, and the rows the
+    kernel must not write left untouched."""
+    import sdag_amd
+    from oracle import sdag_ref
+
+    rng = np.random.default_rng(100 + seed)
+    n_docs = int(rng.integers(1, 7))
+    lens = [int(x) for x in rng.integers(0, 160, n_docs)]
+    sys_len = int(rng.integers(0, 70))
+    spans, qa, L = synthetic_layout(sys_len, lens, int(rng.integers(0, 3)), int(rng.integers(1, 50)))
+    if seed % 2 and n_docs > 1:                      # overlapping spans: later writes only ever add pairs
+        spans[1] = (max(spans[0][0], spans[1][0] - 7), spans[1][1])
+    nbr = None
+    if seed % 3:
+        nbr = [[int(x) for x in rng.integers(-1, n_docs + 1, int(rng.integers(0, 3)))] for _ in range(n_docs)]
+    Hq, Hkv = [(4, 1), (8, 2), (6, 2)][seed % 3]
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(1, Hq, L, 128, generator=g).to(torch.bfloat16)
+    k = torch.randn(1, Hkv, L, 128, generator=g).to(torch.bfloat16)
+    v = (torch.randn(1, Hkv, L, 128, generator=g) * (1.0 if seed % 2 else 30.0)).to(torch.bfloat16)
+    mask = torch.from_numpy(sdag_ref.mask_from_spans(L, sys_len, spans, qa, nbr))
+    ref = sdag_ref.masked_attention(q, k, v, mask, 128 ** -0.5)
+    for n_streams, T in ((1, 0), (3, 2), (64, 0), (200, 1)):
+        d = sdag_amd.from_spans(L, sys_len, spans, qa, nbr, max_items_per_unit=T, n_streams=n_streams)
+        o = sdag_amd.sdag_attention(q.to(DEV), k.to(DEV), v.to(DEV), d, out_dtype=torch.float32).cpu()
+        assert torch.isfinite(o).all() and _rel_err(o, ref) <= 1e-3, (n_streams, T)
+        ob = torch.full((1, L + 3, Hq, 128), 7.0, dtype=torch.bfloat16, device=DEV)
+        sdag_amd.sdag_attention(q.to(DEV), k.to(DEV), v.to(DEV), d, out=ob[:, :L])
+        assert torch.equal(ob[:, :L].cpu(), o.to(torch.bfloat16)), (n_streams, T)
+        assert (ob[:, L:] == 7.0).all()

@@ -75,6 +75,26 @@ if __name__ == "__main__":
         for T in (4, 6, 8, 11, 16, 32, 64):
             d = sdag_amd.from_spans(L, 60, spans, qa, None, max_items_per_unit=T)
             print(f"cfg3 T={T}: units={d.n_units} items={d.n_items} slots={d.n_slots} -> {timeit(d, L):.1f} us", flush=True)
+    if which == "cfg4batch":
+        K = 20
+        spans, qa, L = layout(60, K, 380, 1, 30)
+        nbr = [[(i + 1) % K, (i + 2) % K] for i in range(K)]
+        for B in (4, 8):
+            descs = [sdag_amd.from_spans(L, 60, spans, qa, nbr, max_items_per_unit=64) for _ in range(B)]
+            bd = sdag_amd.BatchDescriptor(descs)
+            q = torch.randn((B, L, 32, 128), device=dev).to(torch.bfloat16).transpose(1, 2)
+            k = torch.randn((B, L, 8, 128), device=dev).to(torch.bfloat16).transpose(1, 2)
+            v = torch.randn((B, L, 8, 128), device=dev).to(torch.bfloat16).transpose(1, 2)
+            o = torch.empty((B, L, 32, 128), device=dev, dtype=torch.bfloat16)
+            call = sdag_amd.BoundBatchAttention(q, k, v, bd, o)
+            call(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5): call()
+            e1.record(); torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) * 1e3 / 5
+            fl = 4 * 128 * descs[0].allowed_pairs * 32
+            print(f"cfg4 batch B={B}: {t:.1f} us/launch = {t / B:.1f} us/query-layer, {fl * B / t / 1e6:.0f} TFLOP/s, pairs={descs[0].allowed_pairs}", flush=True)
     if which in ("all", "cfg4"):
         K = 20
         spans, qa, L = layout(60, K, 380, 1, 30)
