@@ -135,13 +135,85 @@ def _n_tokens(tokenizer, text: str) -> int:
     return len(tokenizer(text, return_tensors="pt").input_ids[0])
 
 
+_TAIL_MARGIN = 8  # characters re-tokenised in front of a cut (the longest look-ahead of the split patterns is 3)
+_local_cache: dict = {}
+
+
+def _tokenizer_is_local(tokenizer) -> bool:
+    """True for fast tokenizers whose text -> token map is a left-to-right scan without look-behind: no
+    normaliser, a split-pattern / byte-level pre-tokeniser that adds no prefix space, BPE inside the pre-tokens
+    (the Llama-3 family).  Only those may count prefix lengths from one tokenisation of the whole prompt."""
+    key = id(tokenizer)
+    if key in _local_cache:
+        return _local_cache[key]
+    ok = False
+    try:
+        if getattr(tokenizer, "is_fast", False):
+            import json
+
+            cfg = json.loads(tokenizer.backend_tokenizer.to_str())
+            pre = cfg.get("pre_tokenizer") or {}
+            parts = pre.get("pretokenizers", [pre]) if pre.get("type") == "Sequence" else [pre]
+            kinds = [p_.get("type") for p_ in parts]
+            ok = (cfg.get("normalizer") is None and (cfg.get("model") or {}).get("type") == "BPE"
+                  and bool(kinds) and set(kinds) <= {"Split", "ByteLevel"} and "ByteLevel" in kinds
+                  and all(not p_.get("add_prefix_space", False) for p_ in parts if p_.get("type") == "ByteLevel")
+                  and all(p_.get("behavior", "Isolated") == "Isolated" and not p_.get("invert", False)
+                          for p_ in parts if p_.get("type") == "Split"))
+    except Exception:
+        ok = False
+    _local_cache[key] = ok
+    return ok
+
+
+def _prefix_token_counts(tokenizer, text: str, cuts: List[int]) -> List[int]:
+    """``len(tokenizer(text[:c]).input_ids)`` for every cut c -- what the reference computes with one full
+    tokenisation per cut (SDAG.py:289-302) -- from ONE tokenisation of ``text`` plus a few characters around each
+    cut.  Pre-tokens that end well before a cut are the same in the prefix and in the whole text (the split
+    pattern scans left to right and looks at most three characters ahead), and byte-level BPE never merges across
+    pre-tokens; the stretch from the last such pre-token to the cut is tokenised on its own.  Tokenizers that are
+    not of that kind take the reference's route."""
+    if not cuts:
+        return []
+    if not _tokenizer_is_local(tokenizer):
+        return [_n_tokens(tokenizer, text[:c]) for c in cuts]
+    import bisect
+
+    enc = tokenizer(text, return_offsets_mapping=True).encodings[0]
+    offs, words, special = enc.offsets, enc.word_ids, enc.special_tokens_mask
+    if any(w is None and not m for w, m in zip(words, special)):  # no pre-token ids: no safe place to cut
+        return [_n_tokens(tokenizer, text[:c]) for c in cuts]
+    n_added = sum(1 for m in special if m)  # what the post-processor adds to any text (BOS ...)
+    ends, upto = [], []                      # char end of every complete pre-token, tokens up to and including it
+    n_content = 0
+    for i, (m, (_, e)) in enumerate(zip(special, offs)):
+        if m:
+            continue
+        n_content += 1
+        nxt = i + 1
+        while nxt < len(offs) and special[nxt]:
+            nxt += 1
+        if nxt == len(offs) or words[nxt] is None or words[nxt] != words[i]:
+            ends.append(e)
+            upto.append(n_content)
+    out = []
+    for c in cuts:
+        j = bisect.bisect_right(ends, c - _TAIL_MARGIN) - 1
+        a, n0 = (ends[j], upto[j]) if j >= 0 else (0, 0)
+        tail = text[a:c]
+        n1 = len(tokenizer(tail, add_special_tokens=False).input_ids) if tail else 0
+        out.append(n_added + n0 + n1)
+    return out
+
+
 def build_rag_chat_and_spans(tokenizer, system_prompt: str, user_template: str, query: str, malicious_docs: List[str],
                              retrieved_docs: list, add_attack_in_rank: int):
     """Prompt string and the token spans of its parts (SDAG.py:216-304).
 
     Returns (chat_str, sys_user_len, doc_token_spans, qa_start, ranked_docs).  Token positions are those of
     prefix tokenisations of ``chat_str`` -- the length in tokens of the text before each boundary -- which is how
-    the reference defines them (SDAG.py:289-302).
+    the reference defines them (SDAG.py:289-302); they are obtained from one tokenisation of the prompt where the
+    tokenizer allows it (``_prefix_token_counts``) instead of the reference's 2K + 2.
     """
     ranked_docs = inject_malicious_docs_into_ranked_list(base_docs=retrieved_docs, malicious_docs=malicious_docs,
                                                          attack_pos=add_attack_in_rank)
@@ -160,10 +232,13 @@ def build_rag_chat_and_spans(tokenizer, system_prompt: str, user_template: str, 
     q_at = chat_str.find("- Question:")
     q_at = len(chat_str) if q_at == -1 else q_at
 
-    sys_user_len = _n_tokens(tokenizer, chat_str[: starts[0] if starts else q_at])
-    spans = [(_n_tokens(tokenizer, chat_str[:at]), _n_tokens(tokenizer, chat_str[: at + len(text)]))
-             for text, at in zip(bullets, starts)]
-    qa_start = _n_tokens(tokenizer, chat_str[:q_at])
+    cuts = [starts[0] if starts else q_at]
+    for text, at in zip(bullets, starts):
+        cuts += [at, at + len(text)]
+    cuts.append(q_at)
+    counts = _prefix_token_counts(tokenizer, chat_str, cuts)
+    sys_user_len, qa_start = counts[0], counts[-1]
+    spans = [(counts[1 + 2 * i], counts[2 + 2 * i]) for i in range(len(bullets))]
     return chat_str, sys_user_len, spans, qa_start, ranked_docs
 
 

@@ -115,3 +115,49 @@ def synthetic_layout(sys_len, doc_lens, gap, qa_len):
         spans.append((pos, pos + n))
         pos += n + gap
     return spans, pos, pos + qa_len
+
+
+LLAMA3_SPLIT = (r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|"
+                r"\s+(?!\S)|\s+")
+
+
+def make_bpe_tokenizer(seed=0, vocab=700):
+    """A byte-level BPE fast tokenizer of the Llama-3 kind (same split pattern, BOS from the post-processor, header
+    / end-of-turn special tokens, a chat template), trained in memory on synthetic text: no file, no download."""
+    import random
+
+    from tokenizers import Regex, Tokenizer, decoders, models, pre_tokenizers, processors, trainers
+    from transformers import PreTrainedTokenizerFast
+
+    rng = random.Random(seed)
+    words = ["".join(rng.choice("abcdefghijklmnopqrstuvwxyzéüñ") for _ in range(rng.randint(1, 8))) for _ in range(300)]
+    ends = ["", "", "", ",", ".", "!", "?", ";", ":", "'s", "'re", "'", ")", "\n", "\n\n", "..", " -", ".\n", "!\n\n", "  "]
+
+    def sentence(n_lo=3, n_hi=20):
+        toks = []
+        for _ in range(rng.randint(n_lo, n_hi)):
+            w = rng.choice(words)
+            r = rng.random()
+            if r < 0.1:
+                w = w.capitalize()
+            if r > 0.88:
+                w = str(rng.randint(0, 999999))
+            toks.append(w + rng.choice(ends))
+        return " ".join(toks)
+
+    tk = Tokenizer(models.BPE())
+    tk.pre_tokenizer = pre_tokenizers.Sequence([
+        pre_tokenizers.Split(Regex(LLAMA3_SPLIT), behavior="isolated", invert=False),
+        pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=False)])
+    tk.decoder = decoders.ByteLevel()
+    specials = ["<|begin_of_text|>", "<|start_header_id|>", "<|end_header_id|>", "<|eot_id|>"]
+    tr = trainers.BpeTrainer(vocab_size=vocab, special_tokens=specials, initial_alphabet=pre_tokenizers.ByteLevel.alphabet(),
+                             show_progress=False)
+    tk.train_from_iterator([sentence() for _ in range(3000)], tr)
+    tk.post_processor = processors.TemplateProcessing(
+        single="<|begin_of_text|> $A", special_tokens=[("<|begin_of_text|>", tk.token_to_id("<|begin_of_text|>"))])
+    fast = PreTrainedTokenizerFast(tokenizer_object=tk, bos_token="<|begin_of_text|>", eos_token="<|eot_id|>")
+    fast.chat_template = (
+        "{% for m in messages %}<|start_header_id|>{{ m['role'] }}<|end_header_id|>\n\n{{ m['content'] }}<|eot_id|>{% endfor %}"
+        "{% if add_generation_prompt %}<|start_header_id|>assistant<|end_header_id|>\n\n{% endif %}")
+    return fast, sentence

@@ -78,6 +78,64 @@ def test_build_rag_chat_and_spans_semantics(SDAG):
     assert spans == [] and sys_len == qa
 
 
+def _reference_method_spans(tok, chat, bullets):
+    """The reference's own way (SDAG.py:274-302): one tokenisation of the text before every boundary."""
+    n = lambda t: len(tok(t, return_tensors="pt").input_ids[0])
+    starts, cursor = [], 0
+    for text in bullets:
+        at = chat.find(text, cursor)
+        at = cursor if at == -1 else at
+        starts.append(at)
+        cursor = at + len(text)
+    q_at = chat.find("- Question:")
+    q_at = len(chat) if q_at == -1 else q_at
+    sys_len = n(chat[: starts[0] if starts else q_at])
+    spans = [(n(chat[:at]), n(chat[: at + len(t)])) for t, at in zip(bullets, starts)]
+    return sys_len, spans, n(chat[:q_at])
+
+
+def test_single_pass_spans_equal_prefix_tokenisations(SDAG):
+    """Token spans from ONE tokenisation of the prompt against the reference's 2K + 2 prefix tokenisations, on a
+    byte-level BPE tokenizer of the Llama-3 kind: documents that end in punctuation (which the split pattern glues
+    to the following blank line), contractions, digit runs, accents, inner blank lines; and every cut position of
+    a prompt, not only the ones the pipeline uses."""
+    import time
+
+    from helpers import make_bpe_tokenizer
+
+    tok, sentence = make_bpe_tokenizer(seed=3)
+    assert SDAG._tokenizer_is_local(tok)
+    rng = random.Random(11)
+    t_fast = t_ref = 0.0
+    for trial in range(25):
+        docs = [sentence(5, 60) for _ in range(rng.randint(1, 8))]
+        if trial % 5 == 0:
+            docs.insert(1, "")
+        mal = [sentence(3, 10)] if trial % 3 == 0 else []
+        query = sentence(2, 6) + "?"
+        t0 = time.perf_counter()
+        chat, sys_len, spans, qa, ranked = SDAG.build_rag_chat_and_spans(tok, "SYS " + sentence(2, 5), SDAG.USER_RAG_PROMPT,
+                                                                         query, mal, docs, 1)
+        t_fast += time.perf_counter() - t0
+        bullets = [f"- {d.strip()}" for d in ranked if d and d.strip()]
+        t0 = time.perf_counter()
+        want = _reference_method_spans(tok, chat, bullets)
+        t_ref += time.perf_counter() - t0
+        assert (sys_len, spans, qa) == want, trial
+        assert qa <= len(tok(chat).input_ids)
+    print(f"spans: single pass {t_fast * 1e3:.1f} ms, prefix tokenisations {t_ref * 1e3:.1f} ms over 25 prompts")
+    # every cut of one prompt (the pipeline only cuts at bullets, but the count must hold anywhere)
+    chat = tok.apply_chat_template([{"role": "user", "content": "It's 12345 units!\n\n- we're here...\n\n\n- x'r  y  \n z"}],
+                                   tokenize=False, add_generation_prompt=True)
+    cuts = list(range(len(chat) + 1))
+    got = SDAG._prefix_token_counts(tok, chat, cuts)
+    assert got == [len(tok(chat[:c]).input_ids) for c in cuts]
+    # a tokenizer that is not of that kind takes the reference's route (and still agrees with it)
+    toy = ToyTokenizer()
+    assert not SDAG._tokenizer_is_local(toy)
+    assert SDAG._prefix_token_counts(toy, "a b c d", [0, 3, 7]) == [len(toy("a b c d"[:c]).input_ids[0]) for c in (0, 3, 7)]
+
+
 def test_ranked_list_injection_rules():
     from sdag_amd.ranked_list import inject_malicious_docs_into_ranked_list as inj
 
