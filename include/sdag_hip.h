@@ -127,6 +127,26 @@ int sdag_attn_fwd_batch(const void* q, const void* k, const void* v, void* o,
                         void* workspace, int64_t workspace_bytes, int out_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Single-token attention over the key/value cache: O = softmax(q K^T * scale) V for ONE query position per
+ * sequence, every cached key allowed, grouped-query heads.  Replaces the attention of the decode steps
+ *   model(input_ids=generated[:, -1:], past_key_values=past_key_values, use_cache=True)   (SDAG.py:191-199)
+ * to which the reference passes no mask.
+ *
+ * q [B, Hq, 1, D] (element strides q_sb, q_sh), k / v [B, Hkv, S, D] (strides _sb, _sh, _sl), o [B, 1, Hq, D]
+ * (strides o_sb, o_sh), bf16, D = 128 contiguous, strides multiples of 8 elements, pointers 16-byte aligned;
+ * o bf16 or fp32.  workspace: at least sdag_decode_workspace_bytes(B, Hq, S) bytes of device scratch.
+ */
+int64_t sdag_decode_workspace_bytes(int B, int Hq, int S);
+
+int sdag_decode_attn(const void* q, const void* k, const void* v, void* o,
+                     int64_t q_sb, int64_t q_sh,
+                     int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                     int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                     int64_t o_sb, int64_t o_sh,
+                     int B, int Hq, int Hkv, int S, int D, float scale,
+                     void* workspace, int64_t workspace_bytes, int out_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Exact inner-product search.  Replaces  scores, indices = index.search(q, top_k)
  * (src/pipeline/retrieval/dense.py:82-84; the arithmetic of the reference is inside faiss).
  *

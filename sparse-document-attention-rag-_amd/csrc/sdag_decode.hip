@@ -1,0 +1,226 @@
+// Single-token attention over the key/value cache for gfx950 (MI355X), bf16 in, fp32 softmax/accumulate.
+//
+// Replaces the attention of the reference's decode steps
+//   out = model(input_ids=generated[:, -1:], past_key_values=past_key_values, use_cache=True)
+// (src/pipeline/sparse_attention_RAG/SDAG.py:191-199): one query token per sequence, every cached key allowed
+// (the reference passes no mask there), grouped-query heads, output [B, 1, Hq, D].
+//
+// The step is a pure stream over K and V (2 * S * D * 2 bytes per key/value head against 4 * G * S * D flops), so
+// it runs on the vector ALUs and is laid out for memory parallelism: one wave per (sequence, key/value head,
+// group of up to 4 query heads, part of the keys).  For every 64 keys of its part a wave
+//   - reads one K row per lane (16 x 16 bytes) and takes the dot products with the (up to) 4 query rows, whose
+//     bf16 pairs sit in scalar registers (v_dot2c_f32_bf16: exact products, fp32 sums);
+//   - does the online-softmax bookkeeping per query head with wave reductions;
+//   - accumulates P V with each lane owning two output columns: V rows are read coalesced (one 256-byte row per
+//     wave instruction), the probability of a key comes out of its lane with v_readlane.
+// Parts are merged by a second kernel (log-sum-exp weights).
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace sdag {
+namespace {
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+#define AS4 __attribute__((address_space(4)))
+
+constexpr int D = 128;
+constexpr int GW = 4;            // query heads per wave
+constexpr int PART_STRIDE = D + 2;  // floats per partial: o[128], m, l
+
+struct DecodeParams {
+    const unsigned short* q;
+    const unsigned short* k;
+    const unsigned short* v;
+    void* o;
+    int64_t q_sb, q_sh, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sh;
+    int B, Hq, Hkv, G, HG, S;
+    int n_parts, groups_per_part;  // a part is groups_per_part groups of 64 keys
+    int out_f32;
+    float c;       // scale * log2(e)
+    float* part;   // [B][Hq][n_parts][PART_STRIDE]
+};
+
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off));
+    return x;
+}
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    return x;
+}
+
+__global__ __launch_bounds__(64) void sdag_decode_main(const DecodeParams p) {
+    const int lane = threadIdx.x;
+    int bid = blockIdx.x;
+    const int part = bid % p.n_parts; bid /= p.n_parts;
+    const int hg = bid % p.HG; bid /= p.HG;
+    const int kvh = bid % p.Hkv;
+    const int b = bid / p.Hkv;
+    const int h0 = kvh * p.G + hg * GW;              // first query head of this wave
+    const int nh = min(GW, p.G - hg * GW);           // heads it really has
+
+    // The query rows are wave-uniform: bf16 pairs through scalar loads (rows beyond nh repeat the last one).
+    const AS4 unsigned* qrow[GW];
+#pragma unroll
+    for (int j = 0; j < GW; ++j)
+        qrow[j] = (const AS4 unsigned*)(p.q + (int64_t)b * p.q_sb + (int64_t)(h0 + min(j, nh - 1)) * p.q_sh);
+
+    const unsigned short* kh = p.k + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh;
+    const unsigned short* vh = p.v + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh;
+
+    float m[GW], l[GW], o0[GW], o1[GW];  // running max / sum (uniform), this lane's two output columns
+#pragma unroll
+    for (int j = 0; j < GW; ++j) { m[j] = -INFINITY; l[j] = 0.f; o0[j] = 0.f; o1[j] = 0.f; }
+
+    const int g_begin = part * p.groups_per_part;
+    const int g_end = min(g_begin + p.groups_per_part, (p.S + 63) / 64);
+    for (int g = g_begin; g < g_end; ++g) {
+        const int key = g * 64 + lane;
+        const bool live = key < p.S;
+        // ---- scores of this lane's key against the query rows
+        const u32x4* krow = reinterpret_cast<const u32x4*>(kh + (int64_t)min(key, p.S - 1) * p.k_sl);
+        float s[GW] = {0.f, 0.f, 0.f, 0.f};
+        // the query words are re-read through the scalar cache for every group of keys: 256 of them do not fit
+        // the scalar registers, and keeping the pointers opaque stops the compiler from hoisting the loads
+        // out of the loop into spilled registers
+#pragma unroll
+        for (int j = 0; j < GW; ++j) asm volatile("" : "+s"(qrow[j]));
+#pragma unroll
+        for (int ch = 0; ch < 16; ++ch) {
+            const u32x4 kk = krow[ch];
+            const unsigned kw[4] = {kk.x, kk.y, kk.z, kk.w};
+#pragma unroll
+            for (int j = 0; j < GW; ++j) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned qw = qrow[j][ch * 4 + e];
+                    s[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, kw[e]),
+                                                           __builtin_bit_cast(bf16x2, qw), s[j], false);
+                }
+            }
+        }
+        // ---- online softmax per head (base-2 exponent of scaled scores)
+        float pr[GW];
+#pragma unroll
+        for (int j = 0; j < GW; ++j) {
+            const float x = live ? s[j] * p.c : -INFINITY;
+            const float m_new = fmaxf(m[j], wave_max(x));
+            const float alpha = __builtin_amdgcn_exp2f(m[j] - m_new);  // m = -inf on the first group: 0
+            pr[j] = __builtin_amdgcn_exp2f(x - m_new);
+            l[j] = l[j] * alpha + wave_sum(pr[j]);
+            o0[j] *= alpha;
+            o1[j] *= alpha;
+            m[j] = m_new;
+        }
+        // ---- O += P V: one coalesced 256-byte V row per key, its probability read out of the key's lane
+        // (lanes past the end of the sequence hold probability 0; their rows are clamped to the last key)
+        const int n_live = min(64, p.S - g * 64);
+        const unsigned* vbase = reinterpret_cast<const unsigned*>(vh) + lane;
+        for (int t0 = 0; t0 < n_live; t0 += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u;
+                const unsigned w = vbase[(int64_t)min(g * 64 + t, p.S - 1) * (p.v_sl / 2)];
+                const float v0 = __uint_as_float(w << 16), v1 = __uint_as_float(w & 0xffff0000u);
+#pragma unroll
+                for (int j = 0; j < GW; ++j) {
+                    const float pj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pr[j]), t));
+                    o0[j] = __builtin_fmaf(pj, v0, o0[j]);
+                    o1[j] = __builtin_fmaf(pj, v1, o1[j]);
+                }
+            }
+        }
+    }
+    // ---- this part's result
+#pragma unroll
+    for (int j = 0; j < GW; ++j) {
+        if (j >= nh) break;
+        float* dst = p.part + (((int64_t)b * p.Hq + h0 + j) * p.n_parts + part) * PART_STRIDE;
+        reinterpret_cast<float2*>(dst)[lane] = make_float2(o0[j], o1[j]);
+        if (lane == 0) {
+            dst[D] = m[j];
+            dst[D + 1] = l[j];
+        }
+    }
+}
+
+// One block of 128 threads per (sequence, query head): log-sum-exp merge of the parts, one column per thread.
+__global__ __launch_bounds__(128) void sdag_decode_merge(const DecodeParams p) {
+    const int hq = blockIdx.x % p.Hq, b = blockIdx.x / p.Hq;
+    const int col = threadIdx.x;
+    const float* src = p.part + ((int64_t)b * p.Hq + hq) * p.n_parts * PART_STRIDE;
+    float mmax = -INFINITY;
+    for (int t = 0; t < p.n_parts; ++t) mmax = fmaxf(mmax, src[t * PART_STRIDE + D]);
+    float acc = 0.f, den = 0.f;
+    for (int t = 0; t < p.n_parts; ++t) {
+        const float w = __builtin_amdgcn_exp2f(src[t * PART_STRIDE + D] - mmax);  // empty part: m = -inf -> 0
+        den += w * src[t * PART_STRIDE + D + 1];
+        acc += w * src[t * PART_STRIDE + col];
+    }
+    const float r = acc / den;
+    const int64_t oi = (int64_t)b * p.o_sb + (int64_t)hq * p.o_sh + col;
+    if (p.out_f32)
+        reinterpret_cast<float*>(p.o)[oi] = r;
+    else
+        reinterpret_cast<__bf16*>(p.o)[oi] = (__bf16)r;
+}
+
+void plan(int S, int* n_parts, int* groups_per_part) {
+    const int groups = (S + 63) / 64;
+    const int gpp = (groups + 127) / 128;  // at most 128 parts per head
+    *groups_per_part = gpp;
+    *n_parts = (groups + gpp - 1) / gpp;
+}
+
+}  // namespace
+}  // namespace sdag
+
+using namespace sdag;
+
+extern "C" int64_t sdag_decode_workspace_bytes(int B, int Hq, int S) {
+    if (B <= 0 || Hq <= 0 || S <= 0) return -1;
+    int n_parts, gpp;
+    plan(S, &n_parts, &gpp);
+    return (((int64_t)B * Hq * n_parts * PART_STRIDE * (int64_t)sizeof(float)) + 255) & ~255ll;
+}
+
+extern "C" int sdag_decode_attn(const void* q, const void* k, const void* v, void* o,
+                                int64_t q_sb, int64_t q_sh,
+                                int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                                int64_t o_sb, int64_t o_sh,
+                                int B, int Hq, int Hkv, int S, int Dh, float scale,
+                                void* workspace, int64_t workspace_bytes_, int out_dtype, void* stream) {
+    if (Dh != D) return fail(SDAG_ERR_ARG, "head_dim %d not supported (only 128)", Dh);
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || S <= 0 || Hq % Hkv) return fail(SDAG_ERR_ARG, "bad B/Hq/Hkv/S");
+    if (!(scale > 0.f)) return fail(SDAG_ERR_ARG, "scale must be positive");
+    if (out_dtype != SDAG_OUT_BF16 && out_dtype != SDAG_OUT_F32) return fail(SDAG_ERR_ARG, "bad out_dtype");
+    if (!q || !k || !v || !o) return fail(SDAG_ERR_ARG, "NULL tensor pointer");
+    const int64_t strides[] = {q_sb, q_sh, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sh};
+    for (int64_t st : strides)
+        if (st < 0 || (st & 7)) return fail(SDAG_ERR_ARG, "strides must be non-negative multiples of 8 elements");
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return fail(SDAG_ERR_ARG, "tensor pointers must be 16-byte aligned");
+    const int64_t need = sdag_decode_workspace_bytes(B, Hq, S);
+    if (!workspace || workspace_bytes_ < need) return fail(SDAG_ERR_CAPACITY, "workspace needs %lld bytes", (long long)need);
+    DecodeParams p;
+    p.q = (const unsigned short*)q; p.k = (const unsigned short*)k; p.v = (const unsigned short*)v; p.o = o;
+    p.q_sb = q_sb; p.q_sh = q_sh; p.k_sb = k_sb; p.k_sh = k_sh; p.k_sl = k_sl;
+    p.v_sb = v_sb; p.v_sh = v_sh; p.v_sl = v_sl; p.o_sb = o_sb; p.o_sh = o_sh;
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.G = Hq / Hkv; p.HG = (p.G + GW - 1) / GW; p.S = S;
+    plan(S, &p.n_parts, &p.groups_per_part);
+    p.out_f32 = out_dtype == SDAG_OUT_F32;
+    p.c = scale * 1.4426950408889634f;
+    p.part = (float*)workspace;
+    const int64_t blocks = (int64_t)B * Hkv * p.HG * p.n_parts;
+    if (blocks > 0x7fffffff) return fail(SDAG_ERR_ARG, "grid too large");
+    hipLaunchKernelGGL(sdag_decode_main, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, p);
+    SDAG_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(sdag_decode_merge, dim3((unsigned)(B * Hq)), dim3(128), 0, (hipStream_t)stream, p);
+    SDAG_HIP_CHECK(hipGetLastError());
+    return SDAG_OK;
+}

@@ -43,6 +43,8 @@ SIGNATURES = {
     "sdag_batch_build": (i32, [vp, i32, i32, vp, i64, c_i64p]),
     "sdag_attn_batch_workspace_bytes": (i64, [vp, i32, i32]),
     "sdag_attn_fwd_batch": (i32, [vp, vp, vp, vp] + [i64] * 12 + [i32] * 5 + [ctypes.c_float, vp, vp, vp, i64, i32, vp]),
+    "sdag_decode_workspace_bytes": (i64, [i32, i32, i32]),
+    "sdag_decode_attn": (i32, [vp, vp, vp, vp] + [i64] * 10 + [i32] * 5 + [ctypes.c_float, vp, i64, i32, vp]),
     "sdag_dense_workspace_bytes": (i64, [i32, i64, i32, i32]),
     "sdag_dense_topk": (i32, [vp, i32, vp, i64, i32, i32, vp, vp, i64, vp, i64, vp]),
     "sdag_topk_merge": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),

@@ -165,3 +165,43 @@ def sdag_attention_batch(query, key, value, batch: BatchDescriptor, scaling: Opt
     out = torch.zeros((B, L, Hq, D), dtype=out_dtype, device=query.device)
     BoundBatchAttention(query, key, value, batch, out, scaling)()
     return out
+
+
+def decode_attention(query, key, value, scaling: Optional[float] = None, out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """Attention of ONE new token per sequence over the whole key/value cache (no mask): the attention of the
+    reference's decode steps (src/pipeline/sparse_attention_RAG/SDAG.py:191-199).
+
+    query [B, Hq, 1, D], key / value [B, Hkv, S, D] bf16 (any batch / head / row strides, D contiguous); returns
+    [B, 1, Hq, D]."""
+    if not (query.is_cuda and key.is_cuda and value.is_cuda):
+        raise RuntimeError("decode_attention runs on the GPU only (no CPU fallback)")
+    if query.dtype != torch.bfloat16 or key.dtype != torch.bfloat16 or value.dtype != torch.bfloat16:
+        raise TypeError("decode_attention takes bf16 query/key/value")
+    B, Hq, Lq, D = query.shape
+    Bk, Hkv, S, Dk = key.shape
+    if Lq != 1 or value.shape != key.shape or Bk != B or Dk != D or S < 1:
+        raise ValueError(f"shape mismatch: q {tuple(query.shape)} k {tuple(key.shape)} v {tuple(value.shape)}")
+    if query.stride(3) != 1:
+        query = query.contiguous()
+    if key.stride(3) != 1:
+        key = key.contiguous()
+    if value.stride(3) != 1:
+        value = value.contiguous()
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError("out_dtype must be bfloat16 or float32")
+    dev = query.device
+    out = torch.empty((B, 1, Hq, D), dtype=out_dtype, device=dev)
+    lib = _lib.lib()
+    ws = _workspace(dev, int(lib.sdag_decode_workspace_bytes(B, Hq, S)))
+    with torch.cuda.device(dev):
+        rc = lib.sdag_decode_attn(
+            query.data_ptr(), key.data_ptr(), value.data_ptr(), out.data_ptr(),
+            query.stride(0), query.stride(1),
+            key.stride(0), key.stride(1), key.stride(2),
+            value.stride(0), value.stride(1), value.stride(2),
+            out.stride(0), out.stride(2),
+            B, Hq, Hkv, S, D, float(D ** -0.5 if scaling is None else scaling),
+            ws.data_ptr(), ws.numel(), _lib.OUT_F32 if out_dtype == torch.float32 else _lib.OUT_BF16,
+            _lib.stream_ptr(dev))
+    _lib.check(rc)
+    return out

@@ -266,8 +266,23 @@ def test_generate_with_custom_mask_on_gpu():
                 return o
 
             model.forward = spy
-            text = SDAG.generate_with_custom_mask(model, Tok(), ids, mask, max_new_tokens=meta["max_new_tokens"])
+            from sdag_amd import hf_attention
+
+            calls = {"n": 0}
+            real_decode = hf_attention.decode_attention
+
+            def counting_decode(*a, **kw):
+                calls["n"] += 1
+                return real_decode(*a, **kw)
+
+            hf_attention.decode_attention = counting_decode
+            try:
+                text = SDAG.generate_with_custom_mask(model, Tok(), ids, mask, max_new_tokens=meta["max_new_tokens"])
+            finally:
+                hf_attention.decode_attention = real_decode
             model.forward = orig
+            # the decode steps ran the key/value-streaming kernel, once per layer and step
+            assert calls["n"] > 0 and calls["n"] % meta["cfg"]["num_hidden_layers"] == 0
             ref_logits = torch.from_numpy(z["prefill_last_logits"])
             scale = float(ref_logits.abs().max())
             assert float((seen["logits"] - ref_logits).abs().max()) <= tol * scale
@@ -351,3 +366,27 @@ def test_attention_random_layouts_streams_and_bf16_rows(seed):
         sdag_amd.sdag_attention(q.to(DEV), k.to(DEV), v.to(DEV), d, out=ob[:, :L])
         assert torch.equal(ob[:, :L].cpu(), o.to(torch.bfloat16)), (n_streams, T)
         assert (ob[:, L:] == 7.0).all()
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,S", [(1, 32, 8, 3100), (2, 8, 2, 777), (1, 4, 4, 1), (3, 6, 1, 65), (1, 2, 1, 8200), (1, 32, 8, 64)])
+def test_decode_attention_matches_fp32_softmax(B, Hq, Hkv, S):
+    """One new token against the whole cache (the reference's decode steps pass no mask): fp32 restatement of
+    transformers' eager attention on the same bf16 inputs; tolerance 1e-3 of max |ref| per head."""
+    import sdag_amd
+
+    g = torch.Generator().manual_seed(S + Hq)
+    q = torch.randn(B, Hq, 1, 128, generator=g).to(torch.bfloat16)
+    k = torch.randn(B, S, Hkv, 128, generator=g).to(torch.bfloat16).transpose(1, 2)      # the cache as a strided view
+    v = (torch.randn(B, Hkv, S, 128, generator=g) * 3).to(torch.bfloat16)
+    if S > 100:
+        k[0, 0, S // 2] = (q[0, 0, 0].float() * 2.5).to(torch.bfloat16)                  # one dominant key
+    G = Hq // Hkv
+    kk = k.float().repeat_interleave(G, dim=1)
+    vv = v.float().repeat_interleave(G, dim=1)
+    scale = 0.09
+    ref = (torch.softmax(q.float() @ kk.transpose(2, 3) * scale, dim=-1) @ vv).transpose(1, 2)  # [B, 1, Hq, D]
+    o = sdag_amd.decode_attention(q.to(DEV), k.to(DEV), v.to(DEV), scaling=scale, out_dtype=torch.float32).cpu()
+    assert o.shape == (B, 1, Hq, 128) and torch.isfinite(o).all()
+    assert _rel_err(o, ref) <= 1e-3
+    ob = sdag_amd.decode_attention(q.to(DEV), k.to(DEV), v.to(DEV), scaling=scale).cpu()
+    assert torch.equal(ob, o.to(torch.bfloat16))

@@ -102,3 +102,29 @@ if __name__ == "__main__":
         for T in (8, 16, 32, 64):
             d = sdag_amd.from_spans(L, 60, spans, qa, nbr, max_items_per_unit=T)
             print(f"cfg4 T={T}: units={d.n_units} items={d.n_items} slots={d.n_slots} pairs={d.allowed_pairs} -> {timeit(d, L):.1f} us", flush=True)
+    if which == "decode":
+        # one new token per sequence against S cached keys; bytes = K and V of the cache read once
+        for (B, Hq, Hkv, S) in ((1, 32, 8, 3100), (1, 32, 8, 8192), (8, 32, 8, 3100), (32, 32, 8, 3100), (1, 32, 8, 32768)):
+            nbuf = 6
+            bufs = []
+            for i in range(nbuf):
+                q = torch.randn((B, Hq, 1, 128), device=dev).to(torch.bfloat16)
+                k = torch.randn((B, Hkv, S, 128), device=dev).to(torch.bfloat16)
+                v = torch.randn((B, Hkv, S, 128), device=dev).to(torch.bfloat16)
+                bufs.append((q, k, v))
+            for q, k, v in bufs: sdag_amd.decode_attention(q, k, v)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 10
+            e0.record()
+            for r in range(reps):
+                for q, k, v in bufs: sdag_amd.decode_attention(q, k, v)
+            e1.record(); torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) * 1e3 / (reps * nbuf)
+            e0.record()
+            for r in range(reps):
+                for q, k, v in bufs: torch.nn.functional.scaled_dot_product_attention(q, k, v, enable_gqa=True)
+            e1.record(); torch.cuda.synchronize()
+            t_sdpa = e0.elapsed_time(e1) * 1e3 / (reps * nbuf)
+            gb = 2 * B * Hkv * S * 128 * 2 / 1e9
+            print(f"decode B={B} Hq={Hq} Hkv={Hkv} S={S}: {t:.1f} us = {gb / t * 1e6:.0f} GB/s  (torch sdpa {t_sdpa:.1f} us)", flush=True)
