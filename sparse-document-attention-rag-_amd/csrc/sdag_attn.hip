@@ -228,27 +228,44 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     // ---- staging geometry: thread covers chunk (tid & 15) of rows (tid >> 4) + 16 i, i = 0..3.
     const int st_row = tid >> 4, st_ch = tid & 15;
     const int st_off = tile_off(st_row, st_ch);  // + 16 * 256 * i for the other rows (swizzle term unchanged)
-    u32x4 kreg[4], vreg[4];
-    // Next-tile rows travel global -> registers -> LDS.  The loads are buffer loads whose descriptor starts at the
-    // tile and ends with the sequence's last row, so rows past L read as zeros and no lane needs its own clamp; the
-    // per-lane offset (row inside the tile, 16-byte chunk) is the same for every tile.
-    const unsigned koff0 = (unsigned)st_row * (unsigned)p.k_sl * 2u + (unsigned)st_ch * 16u;
+    u32x4 vreg[4];
+    // Next-tile rows: K goes straight from global memory into the LDS image (LDS-DMA, one 1 KiB piece = 4 tile rows
+    // per wave instruction, the swizzle applied through the source address); V travels global -> registers -> LDS
+    // because it is converted on the way.  All are buffer loads whose descriptor starts at the tile and ends with
+    // the sequence's last row, so rows past L read as zeros and no lane needs its own clamp; the per-lane offset
+    // (row inside the tile, 16-byte chunk) is the same for every tile.
+    const int kd_ch = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (wave & 3));  // source chunk of this lane's LDS slot
+    const unsigned koff0 = (unsigned)st_row * (unsigned)p.k_sl * 2u + (unsigned)kd_ch * 16u;
     const unsigned voff0 = (unsigned)st_row * (unsigned)p.v_sl * 2u + (unsigned)st_ch * 16u;
     const unsigned kstep = 16u * (unsigned)p.k_sl * 2u, vstep = 16u * (unsigned)p.v_sl * 2u;
-    auto tile_rsrc = [&](const unsigned short* base, int sb, int sh, int sl, int b, int kt, int L) {
-        const int64_t head = (int64_t)b * sb + (int64_t)kvh * sh;          // elements
-        const int64_t tile = (int64_t)kt * KT * sl;                        // elements from the head slice
-        const int64_t bytes = (((int64_t)L - 1) * sl + D - tile) * 2;      // from the tile to the end of row L - 1
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(base + head + tile), 0, (int)bytes, 0x00020000);
+    // Start of this key/value head's slice of sequence b_kv and the byte stride of a tile: recomputed only when a
+    // step belongs to another sequence than the one before (the 64-bit products stay out of the per-step path).
+    int b_kv = -1;
+    const unsigned char* kbase = nullptr;
+    const unsigned char* vbase = nullptr;
+    const unsigned ktile_bytes = (unsigned)KT * (unsigned)p.k_sl * 2u, vtile_bytes = (unsigned)KT * (unsigned)p.v_sl * 2u;
+    auto set_kv_base = [&](int b) {
+        b_kv = b;
+        kbase = reinterpret_cast<const unsigned char*>(p.k + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh);
+        vbase = reinterpret_cast<const unsigned char*>(p.v + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh);
     };
-#define SDAG_STAGE_LOADS(B_, KT_, L_)                                                                         \
+    // Buffer descriptor from the tile's first row to the end of row L - 1 of the slice (below 2^31 bytes: checked
+    // on the host).
+    auto tile_rsrc = [&](const unsigned char* base, unsigned tile_bytes, unsigned row_bytes, int kt, int L) {
+        const unsigned off = (unsigned)kt * tile_bytes;
+        const unsigned bytes = (unsigned)(L - 1) * row_bytes + (unsigned)(D * 2) - off;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base + off), 0, (int)bytes, 0x00020000);
+    };
+#define SDAG_STAGE_LOADS(B_, KT_, L_, BUF_)                                                                   \
     {                                                                                                         \
-        const auto krs = tile_rsrc(p.k, p.k_sb, p.k_sh, p.k_sl, (B_), (KT_), (L_));                           \
-        const auto vrs = tile_rsrc(p.v, p.v_sb, p.v_sh, p.v_sl, (B_), (KT_), (L_));                           \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
-            kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, koff0 + i * kstep, 0, 0)); \
+        if ((B_) != b_kv) set_kv_base(B_);                                                                    \
+        const auto krs = tile_rsrc(kbase, ktile_bytes, (unsigned)p.k_sl * 2u, (KT_), (L_));                   \
+        const auto vrs = tile_rsrc(vbase, vtile_bytes, (unsigned)p.v_sl * 2u, (KT_), (L_));                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
             vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff0 + i * vstep, 0, 0)); \
-        }                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)(smem + (BUF_) * TILE_BYTES + (4 * i + wave) * 1024), \
+                                                 16, koff0 + i * kstep, 0, 0, 0);                             \
     }
     // V goes to LDS as fp16: P V then runs on the f16 MFMA with 11-bit probabilities instead of 8-bit ones.
     // bf16 -> fp16 is exact for 2^-14 <= |v| < 2^16; round-toward-zero conversion saturates larger values
@@ -256,11 +273,9 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     float vmax = 0.f;
 #define SDAG_STAGE_STORE(BUF_)                                                                                \
     {                                                                                                         \
-        unsigned char* kd = smem + (BUF_) * TILE_BYTES + st_off;                                              \
         unsigned char* vd = smem + (2 + (BUF_)) * TILE_BYTES + st_off;                                        \
         vmax = 0.f;                                                                                           \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
-            *reinterpret_cast<u32x4*>(kd + i * 16 * 256) = kreg[i];                                           \
             u32x4 hv;                                                                                         \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                   \
                 const unsigned w = vreg[i][j];                                                                \
@@ -315,7 +330,8 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     float m_run = -INFINITY, l_run = 0.f;
     const float c = p.c;
 
-    // Initial S^T accumulators of a step from its lane-mask image (table offset MOFF_, 0 = every pair allowed).
+    // Initial S^T accumulators of a step from its lane-mask image (table offset MOFF_; 0 = every pair allowed: the
+    // accumulators are left alone and the step's first products start from a constant zero instead).
 #define SDAG_INIT_SCORES(MOFF_)                                                                               \
     {                                                                                                         \
         const int moff_ = (MOFF_);                                                                            \
@@ -336,8 +352,6 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
                     s1[8 + i] = mask_init(md, i);                                                             \
                 }                                                                                             \
             }                                                                                                 \
-        } else {                                                                                              \
-            _Pragma("unroll") for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }                      \
         }                                                                                                     \
     }
     // ---- software pipeline over the stream's steps: the record of the NEXT step is known one iteration ahead,
@@ -347,8 +361,9 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     i32x8 nxt = steps[min(s_begin + 1, s_end - 1)];
     load_q(cur[S_B] + bg, cur[S_RB], cur[S_L]);
     __syncthreads();  // vtag zeroed
-    SDAG_STAGE_LOADS(cur[S_B] + bg, cur[S_KT], cur[S_L]);
+    SDAG_STAGE_LOADS(cur[S_B] + bg, cur[S_KT], cur[S_L], 0);
     SDAG_STAGE_STORE(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the K pieces have landed
     stage_tag(0, 1u);
     // The mask enters as the initial accumulator: 0 where the pair is allowed, -inf where it is not (a finite
     // product added to -inf stays -inf).  Accumulator register i of block kb is key 32 kb + (i & 3) + 8 (i >> 2)
@@ -386,14 +401,32 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
 #if !(SDAG_ABLATE & 2)
         {
             bf16x8 ka[8], kb2[8];
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const int ch = ((2 * ks + h) ^ kf) << 4;
-                ka[ks] = *reinterpret_cast<const bf16x8*>(kb_lds + k_row_off + ch);
-                kb2[ks] = *reinterpret_cast<const bf16x8*>(kb_lds + 32 * 256 + k_row_off + ch);
+#define SDAG_K_READ(KS_)                                                                                      \
+    {                                                                                                         \
+        const int ch_ = ((2 * (KS_) + h) ^ kf) << 4;                                                          \
+        ka[KS_] = *reinterpret_cast<const bf16x8*>(kb_lds + k_row_off + ch_);                                 \
+        kb2[KS_] = *reinterpret_cast<const bf16x8*>(kb_lds + 32 * 256 + k_row_off + ch_);                     \
+    }
+            SDAG_K_READ(0);
+            SDAG_K_READ(1);
+            SDAG_K_READ(2);
+            // A tile without a mask starts its products from a constant zero (no accumulator initialisation).
+            if (cur[S_MOFF]) {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0], qf[0], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[0], qf[0], s1, 0, 0, 0);
+            } else {
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0], qf[0], zero, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[0], qf[0], zero, 0, 0, 0);
             }
+            SDAG_K_READ(3);
+            SDAG_K_READ(4);
+            SDAG_K_READ(5);
+            SDAG_K_READ(6);
+            SDAG_K_READ(7);
+#undef SDAG_K_READ
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
+            for (int ks = 1; ks < 8; ++ks) {
                 s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], s0, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[ks], qf[ks], s1, 0, 0, 0);
             }
@@ -401,11 +434,11 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
             // its own tile again): a vector-memory instruction holds the wave's issue for about as long as three
             // MFMAs run, which is free here and a stall anywhere else.
 #if !(SDAG_ABLATE & 1)
-            SDAG_STAGE_LOADS(nxt[S_B] + bg, nxt[S_KT], nxt[S_L]);
+            SDAG_STAGE_LOADS(nxt[S_B] + bg, nxt[S_KT], nxt[S_L], bufc ^ 1);
 #endif
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);  // 6 ds_read
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 ds_read (6 more ran ahead of the first products)
 #pragma unroll
-            for (int g = 0; g < 5; ++g) {
+            for (int g = 0; g < 4; ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 ds_read
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 buffer load
@@ -415,6 +448,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
 #else
 #pragma unroll
@@ -508,52 +542,51 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         }
 
         STAMP(3);
-        // ---- O^T += V^T P^T.  The transposed reads of one 32-column block of V run ahead of the four MFMAs of the
-        // previous block.
+        // ---- O^T += V^T P^T as 16 pinned groups, one MFMA each: the transposed reads of V run two groups ahead of
+        // the MFMA that consumes them, and every group carries one sixteenth of the staging work (the rows
+        // requested above are converted and written to the other tile buffer; nobody reads that buffer before the
+        // barrier below).  The scheduling barriers keep the compiler from regrouping the reads behind the MFMAs.
 #if !(SDAG_ABLATE & 4)
         {
-            s16x4 va[4][4][2];
-#pragma unroll
-            for (int db = 0; db < 4; ++db)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const int rbase = (32 * kb + 16 * s) * 256;
-                        va[db][2 * kb + s][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4*)(vb_lds + rbase + v_off[db][0]));
-                        va[db][2 * kb + s][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4*)(vb_lds + rbase + 8 * 256 + v_off[db][1]));
-                    }
-#pragma unroll
-            for (int db = 0; db < 4; ++db)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        union { s16x4 hlf[2]; f16x8 full; } u;
-                        u.hlf[0] = va[db][2 * kb + s][0];
-                        u.hlf[1] = va[db][2 * kb + s][1];
-                        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(u.full, pf[kb][s], oacc[db], 0, 0, 0);
-                    }
-            // The rows requested above are converted and written to the other tile buffer from inside this MFMA
-            // stream; nobody reads that buffer before the barrier below.
+            s16x4 va[4][2];
+#define SDAG_PV_READ(I_)                                                                                      \
+    {                                                                                                         \
+        const int db_ = (I_) >> 2, rbase_ = (32 * (((I_) >> 1) & 1) + 16 * ((I_) & 1)) * 256;                 \
+        va[(I_) & 3][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                                            \
+            (__attribute__((address_space(3))) s16x4*)(vb_lds + rbase_ + v_off[db_][0]));                     \
+        va[(I_) & 3][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                                            \
+            (__attribute__((address_space(3))) s16x4*)(vb_lds + rbase_ + 8 * 256 + v_off[db_][1]));           \
+    }
+            SDAG_PV_READ(0);
+            SDAG_PV_READ(1);
 #if !(SDAG_ABLATE & 1)
-            SDAG_STAGE_STORE(bufc ^ 1);
+            unsigned char* vd = smem + (2 + (bufc ^ 1)) * TILE_BYTES + st_off;
+            u32x4 hv;
+            vmax = 0.f;
 #endif
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 1);  // reads of block 0
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < 12; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 1);
-                if (g >= 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 1);
+            for (int i = 0; i < 16; ++i) {
+                if (i + 2 < 16) SDAG_PV_READ(i + 2);
+#if !(SDAG_ABLATE & 1)
+                {
+                    const int li_ = i >> 2, lj_ = i & 3;
+                    const unsigned w = vreg[li_][lj_];
+                    const float f0 = __uint_as_float(w << 16), f1 = __uint_as_float(w & 0xffff0000u);
+                    vmax = max3_abs(vmax, f0, f1);
+                    hv[lj_] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(f0, f1));
+                    if (lj_ == 3) *reinterpret_cast<u32x4*>(vd + li_ * 16 * 256) = hv;
+                }
+#endif
+                {
+                    union { s16x4 hlf[2]; f16x8 full; } u;
+                    u.hlf[0] = va[i & 3][0];
+                    u.hlf[1] = va[i & 3][1];
+                    oacc[i >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(u.full, pf[(i >> 1) & 1][i & 1], oacc[i >> 2], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 1);
-            }
+#undef SDAG_PV_READ
         }
 #else
 #pragma unroll
@@ -567,6 +600,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         SDAG_INIT_SCORES(moff_n);
         stage_tag(bufc ^ 1, seq + 1u);
         STAMP(5);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's K pieces of the next tile have landed
         __syncthreads();
         STAMP(6);
 

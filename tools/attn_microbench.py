@@ -128,3 +128,25 @@ if __name__ == "__main__":
             t_sdpa = e0.elapsed_time(e1) * 1e3 / (reps * nbuf)
             gb = 2 * B * Hkv * S * 128 * 2 / 1e9
             print(f"decode B={B} Hq={Hq} Hkv={Hkv} S={S}: {t:.1f} us = {gb / t * 1e6:.0f} GB/s  (torch sdpa {t_sdpa:.1f} us)", flush=True)
+    if which == "cfg3b":
+        # the bench's attention launch: 32 queries of cfg 3, one descriptor each, 4 rotating sets of tensors (8 GB)
+        spans, qa, L = layout(60, 10, 300, 1, 30)
+        B = 32
+        bd = sdag_amd.BatchDescriptor([sdag_amd.from_spans(L, 60, spans, qa, None, max_items_per_unit=64) for _ in range(B)])
+        calls = []
+        for i in range(4):
+            q = torch.randn((B, L, 32, 128), device=dev).to(torch.bfloat16).transpose(1, 2)
+            k = torch.randn((B, L, 8, 128), device=dev).to(torch.bfloat16).transpose(1, 2)
+            v = torch.randn((B, L, 8, 128), device=dev).to(torch.bfloat16).transpose(1, 2)
+            o = torch.empty((B, L, 32, 128), device=dev, dtype=torch.bfloat16)
+            calls.append(sdag_amd.BoundBatchAttention(q, k, v, bd, o))
+        for c in calls: c()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 8
+        e0.record()
+        for r in range(reps):
+            for c in calls: c()
+        e1.record(); torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e3 / (reps * len(calls))
+        print(f"cfg3 B=32: {t:.1f} us/launch = {t / B:.2f} us/query-layer", flush=True)
