@@ -21,16 +21,19 @@ int fail(int code, const char* fmt, ...);
     } while (0)
 
 // ---- descriptor layout (int32 words) -------------------------------------------------------------
-// A descriptor describes one L x L "may attend" relation at a granularity of 32-row blocks and 64-key
-// tiles.  header | units | items | masks | rbinfo | split | uniform | lane masks | stream offsets | steps
+// A descriptor describes one L x L "may attend" relation as tiles of at most 32 query rows x 64 keys.  The rows are
+// cut into row blocks of up to 32 consecutive rows that start at the boundaries of the prompt's segments (system
+// text, every document, the question), so a block never straddles two documents; the keys a block may attend are
+// covered by 64-key tiles that start at the first allowed key of every run, so a document's tiles start with the
+// document.  header | units | items | masks | rbinfo | split | uniform | lane masks | stream offsets | steps
 constexpr int32_t DESC_MAGIC = 0x47414453;  // "SDAG"
-constexpr int32_t DESC_VERSION = 3;
+constexpr int32_t DESC_VERSION = 4;
 enum : int {
     H_MAGIC = 0,
     H_VERSION = 1,
     H_L = 2,
     H_NRB = 3,        // row blocks
-    H_NKT = 4,        // key tiles
+    H_NKT = 4,        // ceil(L / 64)
     H_NUNITS = 5,     // work units (one workgroup each)
     H_NITEMS = 6,     // (key tile, mask) items over all units
     H_NMASKS = 7,     // partial-tile bit masks
@@ -53,14 +56,15 @@ enum : int {
     H_OFF_STEPS = 24,    // multiple of 8 words
     H_WORDS = 32
 };
-// unit   : 8 words {row_block, item_begin, item_end, slot (-1 = writes the output itself), uniform_rows bits of the
-//          row block, key tile and mask index of the first item, 0}: all a workgroup needs to start loading
+// unit   : 8 words {row block index, item_begin, item_end, slot (-1 = writes the output itself), skip bits of the
+//          row block, first key and mask index of the first item, first row of the row block}
 constexpr int UNIT_WORDS = 8;
-// item   : 2 words {key_tile, mask_index (-1 = every pair of the tile allowed)}
-// mask   : 32 rows x uint64, bit c of row r = row (32*rb + r) may attend key (64*kt + c)
-// rbinfo : 2 words per row block {uniform_rows bits, reserved}
-// split  : 4 words {row_block, first_slot, n_slots, 0}
-// uniform: 1 word per row: its index
+// item   : 2 words {first key of the tile, mask_index (-1 = every valid row of the block may attend all 64 keys)}
+// mask   : 32 rows x uint64, bit c of row r = row (row0 + r) may attend key (key0 + c)
+// rbinfo : 2 words per row block {skip bits: rows that allow nothing or lie beyond the block's last row, first row};
+//          a block ends where the next one starts (the last one at L)
+// split  : 4 words {first row, first_slot, n_slots, rows in the block}
+// uniform: 1 word per row that allows nothing: its index
 // lane mask: the same 32 x 64 bits as a mask, regrouped for the attention kernel: 32 uint64, word 16 kb + i holds for
 //          accumulator register i of key block kb (keys 32 kb .. 32 kb + 31 of the tile) one bit per lane:
 //          bit (r + 32 h) = row r may attend key 32 kb + (i & 3) + 8 (i >> 2) + 4 h
@@ -68,14 +72,14 @@ constexpr int UNIT_WORDS = 8;
 // step   : 8 words, one per (unit, item) in the order a workgroup walks them
 constexpr int STEP_WORDS = 8;
 enum : int {
-    S_KT = 0,     // key tile
+    S_KEY0 = 0,   // first key of the tile
     S_MOFF = 1,   // word offset of the tile's lane mask from the start of the table, 0 = every pair allowed
     S_FLAGS = 2,  // bit 0: first step of its unit, bit 1: last step of its unit
     S_B = 3,      // sequence (0 in a single descriptor)
     S_L = 4,      // length of that sequence
-    S_RB = 5,     // row block
+    S_ROW0 = 5,   // first row of the row block
     S_SLOT = 6,   // partial-result slot (global inside a batch table) or -1
-    S_UBITS = 7   // rows of the row block that allow nothing
+    S_UBITS = 7   // skip bits of the row block: rows whose output this step's unit must not write
 };
 constexpr int DEFAULT_STREAMS = 64;
 
@@ -106,7 +110,7 @@ enum : int {
     BT_OFF_STEPS = 17,
     BT_WORDS = 32
 };
-constexpr int32_t BATCH_VERSION = 2;
+constexpr int32_t BATCH_VERSION = 3;
 inline bool batch_ok(const int32_t* d) { return d && d[BT_MAGIC] == BATCH_MAGIC && d[BT_VERSION] == BATCH_VERSION; }
 
 inline bool desc_ok(const int32_t* d) { return d && d[H_MAGIC] == DESC_MAGIC && d[H_VERSION] == DESC_VERSION; }

@@ -218,8 +218,8 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
 
     // ---- Q fragments: B operand of S^T = K Q^T; lane (r, h) holds Q[row][16 ks + 8 h .. +7].
     bf16x8 qf[8];
-    auto load_q = [&](int b, int rb, int L) {
-        const int row_ld = min(rb * RB + r, L - 1);
+    auto load_q = [&](int b, int row0, int L) {
+        const int row_ld = min(row0 + r, L - 1);
         const unsigned short* qp = p.q + (int64_t)b * p.q_sb + (int64_t)hq * p.q_sh + (int64_t)row_ld * p.q_sl + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
@@ -238,29 +238,28 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     const unsigned koff0 = (unsigned)st_row * (unsigned)p.k_sl * 2u + (unsigned)kd_ch * 16u;
     const unsigned voff0 = (unsigned)st_row * (unsigned)p.v_sl * 2u + (unsigned)st_ch * 16u;
     const unsigned kstep = 16u * (unsigned)p.k_sl * 2u, vstep = 16u * (unsigned)p.v_sl * 2u;
-    // Start of this key/value head's slice of sequence b_kv and the byte stride of a tile: recomputed only when a
-    // step belongs to another sequence than the one before (the 64-bit products stay out of the per-step path).
+    // Start of this key/value head's slice of sequence b_kv: recomputed only when a step belongs to another sequence
+    // than the one before (the 64-bit products stay out of the per-step path).
     int b_kv = -1;
     const unsigned char* kbase = nullptr;
     const unsigned char* vbase = nullptr;
-    const unsigned ktile_bytes = (unsigned)KT * (unsigned)p.k_sl * 2u, vtile_bytes = (unsigned)KT * (unsigned)p.v_sl * 2u;
     auto set_kv_base = [&](int b) {
         b_kv = b;
         kbase = reinterpret_cast<const unsigned char*>(p.k + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh);
         vbase = reinterpret_cast<const unsigned char*>(p.v + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh);
     };
-    // Buffer descriptor from the tile's first row to the end of row L - 1 of the slice (below 2^31 bytes: checked
+    // Buffer descriptor from the tile's first key to the end of row L - 1 of the slice (below 2^31 bytes: checked
     // on the host).
-    auto tile_rsrc = [&](const unsigned char* base, unsigned tile_bytes, unsigned row_bytes, int kt, int L) {
-        const unsigned off = (unsigned)kt * tile_bytes;
+    auto tile_rsrc = [&](const unsigned char* base, unsigned row_bytes, int key0, int L) {
+        const unsigned off = (unsigned)key0 * row_bytes;
         const unsigned bytes = (unsigned)(L - 1) * row_bytes + (unsigned)(D * 2) - off;
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base + off), 0, (int)bytes, 0x00020000);
     };
-#define SDAG_STAGE_LOADS(B_, KT_, L_, BUF_)                                                                   \
+#define SDAG_STAGE_LOADS(B_, KEY0_, L_, BUF_)                                                                   \
     {                                                                                                         \
         if ((B_) != b_kv) set_kv_base(B_);                                                                    \
-        const auto krs = tile_rsrc(kbase, ktile_bytes, (unsigned)p.k_sl * 2u, (KT_), (L_));                   \
-        const auto vrs = tile_rsrc(vbase, vtile_bytes, (unsigned)p.v_sl * 2u, (KT_), (L_));                   \
+        const auto krs = tile_rsrc(kbase, (unsigned)p.k_sl * 2u, (KEY0_), (L_));                   \
+        const auto vrs = tile_rsrc(vbase, (unsigned)p.v_sl * 2u, (KEY0_), (L_));                   \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
             vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff0 + i * vstep, 0, 0)); \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
@@ -293,13 +292,13 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     };
     // Slow path for a V tile with values beyond the fp16 range: every thread reloads its part of the tile and
     // stores it scaled by 2^-e (the probabilities are scaled by 2^e to compensate).
-    auto restage_v_scaled = [&](int buf, int b, int kt, int L, int e) {
+    auto restage_v_scaled = [&](int buf, int b, int key0, int L, int e) {
         const float sc = __uint_as_float((unsigned)(127 - e) << 23);
         unsigned char* vd = smem + (2 + buf) * TILE_BYTES + st_off;
         const char* vh = reinterpret_cast<const char*>(p.v + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int kr = min(kt * KT + st_row + 16 * i, L - 1);
+            const int kr = min(key0 + st_row + 16 * i, L - 1);
             const u32x4 raw = *reinterpret_cast<const u32x4*>(vh + ((int64_t)kr * p.v_sl + st_ch * 8) * 2);
             u32x4 hv;
 #pragma unroll
@@ -359,9 +358,9 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     // meanwhile.
     i32x8 cur = steps[s_begin];
     i32x8 nxt = steps[min(s_begin + 1, s_end - 1)];
-    load_q(cur[S_B] + bg, cur[S_RB], cur[S_L]);
+    load_q(cur[S_B] + bg, cur[S_ROW0], cur[S_L]);
     __syncthreads();  // vtag zeroed
-    SDAG_STAGE_LOADS(cur[S_B] + bg, cur[S_KT], cur[S_L], 0);
+    SDAG_STAGE_LOADS(cur[S_B] + bg, cur[S_KEY0], cur[S_L], 0);
     SDAG_STAGE_STORE(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the K pieces have landed
     stage_tag(0, 1u);
@@ -382,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     for (int it = s_begin; it < s_end; ++it, ++seq) {
         const bool has_next = it + 1 < s_end;
         const i32x8 nn = steps[min(it + 2, s_end - 1)];
-        const int b_cur = cur[S_B] + bg, kt_cur = cur[S_KT], L_cur = cur[S_L];
+        const int b_cur = cur[S_B] + bg, key0_cur = cur[S_KEY0], L_cur = cur[S_L];
         const bool first = (cur[S_FLAGS] & 1) != 0, last = (cur[S_FLAGS] & 2) != 0;
         if (first) {
             m_run = -INFINITY;
@@ -434,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
             // its own tile again): a vector-memory instruction holds the wave's issue for about as long as three
             // MFMAs run, which is free here and a stall anywhere else.
 #if !(SDAG_ABLATE & 1)
-            SDAG_STAGE_LOADS(nxt[S_B] + bg, nxt[S_KT], nxt[S_L], bufc ^ 1);
+            SDAG_STAGE_LOADS(nxt[S_B] + bg, nxt[S_KEY0], nxt[S_L], bufc ^ 1);
 #endif
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 ds_read (6 more ran ahead of the first products)
 #pragma unroll
@@ -456,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
 #endif
         STAMP(1);
         // The unit's last product is issued: its Q registers are free for the next unit's rows.
-        if (last && has_next) load_q(nxt[S_B] + bg, nxt[S_RB], nxt[S_L]);
+        if (last && has_next) load_q(nxt[S_B] + bg, nxt[S_ROW0], nxt[S_L]);
         // Touch the four 64-byte lines of the next step's lane mask now, so that the real loads further down
         // find them in the scalar cache.
         const int moff_n = nxt[S_MOFF];
@@ -472,7 +471,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
             if ((tg >> 8) == seq) ve = min((int)(tg & 0xffu) - 142, 15);
         }
         if (ve > 0) {
-            restage_v_scaled(bufc, b_cur, kt_cur, L_cur, ve);
+            restage_v_scaled(bufc, b_cur, key0_cur, L_cur, ve);
             __syncthreads();
         }
         // ---- online softmax (per query = per lane, halves combined by one exchange).  The running maximum is only
@@ -607,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         // ---- end of a unit.  O^T register i of block db is column d = 32 db + (i & 3) + 8 (i >> 2) + 4 h of the
         // lane's row.
         if (last) {
-            const int rb = cur[S_RB];
+            const int row0 = cur[S_ROW0];
             const int slot = cur[S_SLOT];
             const unsigned ubits = (unsigned)cur[S_UBITS];
             if (slot >= 0) {
@@ -628,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
                     }
                 }
             } else if (p.out_f32) {
-                const int row = rb * RB + r;
+                const int row = row0 + r;
                 if (head_ok && row < L_cur && !((ubits >> r) & 1u) && l_run > 0.f) {
                     const float inv = 1.0f / l_run;
                     float* op = reinterpret_cast<float*>(p.o) + (int64_t)b_cur * p.o_sb + (int64_t)row * p.o_sl + (int64_t)hq * p.o_sh;
@@ -661,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
                 for (int j = 0; j < 8; ++j) {
                     const int rr = 4 * j + (lane >> 4);
                     const u32x4 w = *reinterpret_cast<const u32x4*>(stg + rr * 256 + ((ch ^ (rr & 15)) << 4));
-                    const int row = rb * RB + rr;
+                    const int row = row0 + rr;
                     if (head_ok && row < L_cur && !((ubits >> rr) & 1u))
                         *reinterpret_cast<u32x4*>(ob + (int64_t)row * p.o_sl) = w;
                 }
@@ -706,11 +705,11 @@ __global__ __launch_bounds__(256) void sdag_attn_combine(const AttnParams p, int
             slot_base = b * p.n_slots;
         }
         const int32_t* sp = desc + desc[H_OFF_SPLIT] + e * 4;
-        const int rb = sp[0], first = slot_base + sp[1], n = sp[2];
+        const int first = slot_base + sp[1], n = sp[2];
         // thread -> row (tid >> 3), 16 columns starting at (tid & 7) * 16
         const int r = tid >> 3, c0 = (tid & 7) * 16;
-        const int row = rb * RB + r;
-        if (row >= desc[H_L]) return;
+        const int row = sp[0] + r;
+        if (r >= sp[3]) return;
         float mmax = -INFINITY;
         for (int s = 0; s < n; ++s) {
             const int64_t prow = ((int64_t)(first + s) * p.Hq + hq) * RB + r;
@@ -799,7 +798,8 @@ __global__ __launch_bounds__(256) void sdag_attn_combine(const AttnParams p, int
 __global__ __launch_bounds__(256) void sdag_mask_expand(const int32_t* desc, unsigned char* out) {
     const int L = desc[H_L];
     const int rb = blockIdx.x;
-    const int r0 = rb * RB, rows = min(RB, L - r0);
+    const int32_t* rbinfo = desc + desc[H_OFF_RBINFO];
+    const int r0 = rbinfo[2 * rb + 1], rows = (rb + 1 < desc[H_NRB] ? rbinfo[2 * rb + 3] : L) - r0;
     const int tid = threadIdx.x;
     for (int64_t i = tid; i < (int64_t)rows * L; i += 256) out[(int64_t)r0 * L + i] = 0;
     __syncthreads();
@@ -810,10 +810,10 @@ __global__ __launch_bounds__(256) void sdag_mask_expand(const int32_t* desc, uns
     for (int u = 0; u < n_units; ++u) {
         if (units[u * UNIT_WORDS] != rb) continue;
         for (int it = units[u * UNIT_WORDS + 1]; it < units[u * UNIT_WORDS + 2]; ++it) {
-            const int kt = items[it * 2], mi = items[it * 2 + 1];
+            const int key0 = items[it * 2], mi = items[it * 2 + 1];
             for (int e = tid; e < RB * KT; e += 256) {
                 const int r = e >> 6, cidx = e & 63;
-                const int col = kt * KT + cidx;
+                const int col = key0 + cidx;
                 if (r >= rows || col >= L) continue;
                 const bool on = mi < 0 ? true : ((masks[(int64_t)mi * RB + r] >> cidx) & 1ull);
                 if (on) out[(int64_t)(r0 + r) * L + col] = 1;

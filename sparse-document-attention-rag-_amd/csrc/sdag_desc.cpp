@@ -40,8 +40,8 @@ inline void set_range(uint64_t* row_bits, int a, int b) {  // columns [a, b), b 
 
 // One unit as the scheduler sees it.
 struct SchedUnit {
-    int32_t b, rb, item_begin, item_end, slot, ubits, L;
-    const int32_t* items;  // the sequence's {key tile, mask index} pairs
+    int32_t b, row0, item_begin, item_end, slot, ubits, L;
+    const int32_t* items;  // the sequence's {first key, mask index} pairs
     int64_t lmask_base;    // word offset (from the start of the table the steps live in) of that sequence's lane masks
 };
 
@@ -66,12 +66,12 @@ void build_schedule(const std::vector<SchedUnit>& units, int n_streams, int32_t*
             for (int it = u.item_begin; it < u.item_end; ++it, ++n) {
                 int32_t* w = steps + n * STEP_WORDS;
                 const int32_t mi = u.items[2 * it + 1];
-                w[S_KT] = u.items[2 * it];
+                w[S_KEY0] = u.items[2 * it];
                 w[S_MOFF] = mi < 0 ? 0 : (int32_t)(u.lmask_base + (int64_t)mi * 64);
                 w[S_FLAGS] = (it == u.item_begin ? 1 : 0) | (it + 1 == u.item_end ? 2 : 0);
                 w[S_B] = u.b;
                 w[S_L] = u.L;
-                w[S_RB] = u.rb;
+                w[S_ROW0] = u.row0;
                 w[S_SLOT] = u.slot;
                 w[S_UBITS] = u.ubits;
             }
@@ -95,16 +95,39 @@ void lane_mask_image(const uint64_t* rows, uint64_t* out) {
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
-// fill(rb, bits): bits is RB * nkt words, zeroed by the caller; bits[r * nkt + t].
-using FillFn = std::function<void(int, uint64_t*)>;
+// fill(row0, rows, bits): the allowed keys of rows row0 .. row0 + rows - 1 as bit rows of nw = ceil(L / 64) words,
+// bits[r * nw + w], zeroed by the caller.
+using FillFn = std::function<void(int, int, uint64_t*)>;
 
-int emit(int L, const FillFn& fill, int max_items_per_unit, int n_streams, int32_t* out, int64_t cap_words, int64_t* n_words) {
+// 64 bits of a bit row starting at bit `pos` (bits at and beyond 64 * nw read as zero).
+inline uint64_t window(const uint64_t* row, int nw, int pos) {
+    const int w = pos >> 6, sh = pos & 63;
+    uint64_t x = w < nw ? row[w] >> sh : 0;
+    if (sh && w + 1 < nw) x |= row[w + 1] << (64 - sh);
+    return x;
+}
+
+// `cuts`: positions where a row block must start (any order, duplicates and out-of-range values allowed).
+int emit(int L, std::vector<int> cuts, const FillFn& fill, int max_items_per_unit, int n_streams, int32_t* out,
+         int64_t cap_words, int64_t* n_words) {
     if (n_streams <= 0) n_streams = DEFAULT_STREAMS;
     if (n_streams > 65536) return fail(SDAG_ERR_ARG, "too many streams");
-    const int nrb = (L + RB - 1) / RB;
-    const int nkt = (L + KT - 1) / KT;
-    std::vector<uint64_t> bits((size_t)RB * std::max(nkt, 1));
-    std::vector<int32_t> items;            // {kt, mask}
+    const int nw = (L + KT - 1) / KT;
+    // ---- row blocks
+    cuts.push_back(0);
+    cuts.push_back(L);
+    std::sort(cuts.begin(), cuts.end());
+    std::vector<int32_t> rb_row0;
+    for (size_t i = 0; i + 1 < cuts.size(); ++i) {
+        const int a = cuts[i], b = cuts[i + 1];
+        if (a < 0 || b > L || b <= a) continue;
+        for (int r = a; r < b; r += RB) rb_row0.push_back(r);
+    }
+    const int nrb = (int)rb_row0.size();
+    auto rb_rows = [&](int rb) { return (rb + 1 < nrb ? rb_row0[rb + 1] : L) - rb_row0[rb]; };
+
+    std::vector<uint64_t> bits((size_t)RB * std::max(nw, 1)), uni_cols((size_t)std::max(nw, 1));
+    std::vector<int32_t> items;            // {key0, mask}
     std::vector<int32_t> rb_item_begin(nrb + 1, 0);
     std::vector<uint64_t> masks;           // 32 words per mask
     std::vector<int32_t> rbinfo((size_t)nrb * 2, 0);
@@ -112,35 +135,43 @@ int emit(int L, const FillFn& fill, int max_items_per_unit, int n_streams, int32
     int64_t pairs = 0;
 
     for (int rb = 0; rb < nrb; ++rb) {
+        const int row0 = rb_row0[rb], rows = rb_rows(rb);
         std::fill(bits.begin(), bits.end(), 0ull);
-        fill(rb, bits.data());
-        uint32_t uni = 0;
-        const int rows = std::min(RB, L - rb * RB);
+        fill(row0, rows, bits.data());
+        std::fill(uni_cols.begin(), uni_cols.end(), 0ull);
+        uint32_t skip = rows < RB ? ~0u << rows : 0u;
         for (int r = 0; r < rows; ++r) {
             uint64_t any = 0;
-            for (int t = 0; t < nkt; ++t) any |= bits[(size_t)r * nkt + t];
-            if (!any) {
-                uni |= 1u << r;
-                uniform.push_back(rb * RB + r);
-            }
-        }
-        rbinfo[(size_t)rb * 2] = (int32_t)uni;
-        for (int t = 0; t < nkt; ++t) {
-            uint64_t any = 0, all = ~0ull;
-            for (int r = 0; r < RB; ++r) {
-                const uint64_t w = bits[(size_t)r * nkt + t];
+            for (int t = 0; t < nw; ++t) {
+                const uint64_t w = bits[(size_t)r * nw + t];
                 any |= w;
-                all &= w;
+                uni_cols[t] |= w;
                 pairs += __builtin_popcountll(w);
             }
-            if (!any) continue;
-            items.push_back(t);
+            if (!any) {
+                skip |= 1u << r;
+                uniform.push_back(row0 + r);
+            }
+        }
+        rbinfo[(size_t)rb * 2] = (int32_t)skip;
+        rbinfo[(size_t)rb * 2 + 1] = row0;
+        // tiles: 64 keys from the first key some row of the block may attend, then from the next such key, ...
+        for (int c = 0; c < L;) {
+            int t = c >> 6;
+            uint64_t w = t < nw ? uni_cols[t] & (~0ull << (c & 63)) : 0;
+            while (!w && ++t < nw) w = uni_cols[t];
+            if (!w) break;
+            const int key0 = t * 64 + __builtin_ctzll(w);
+            uint64_t all = key0 + KT <= L ? ~0ull : 0ull;
+            for (int r = 0; r < rows; ++r) all &= window(bits.data() + (size_t)r * nw, nw, key0);
+            items.push_back(key0);
             if (all == ~0ull) {
                 items.push_back(-1);
             } else {
                 items.push_back((int32_t)(masks.size() / RB));
-                for (int r = 0; r < RB; ++r) masks.push_back(bits[(size_t)r * nkt + t]);
+                for (int r = 0; r < RB; ++r) masks.push_back(r < rows ? window(bits.data() + (size_t)r * nw, nw, key0) : 0ull);
             }
+            c = key0 + KT;
         }
         rb_item_begin[rb + 1] = (int32_t)(items.size() / 2);
     }
@@ -167,12 +198,12 @@ int emit(int L, const FillFn& fill, int max_items_per_unit, int n_streams, int32
         }
         const int nch = (n + T - 1) / T;
         const int per = (n + nch - 1) / nch;
-        split.push_back(rb);
+        split.push_back(rb_row0[rb]);
         split.push_back(n_slots);
         int made = 0;
         for (int s = b; s < e; s += per, ++made) units.push_back({rb, s, std::min(e, s + per), n_slots + made});
         split.push_back(made);
-        split.push_back(0);
+        split.push_back(rb_rows(rb));
         n_slots += made;
     }
     std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& c) { return (a.e - a.b) > (c.e - c.b); });
@@ -200,7 +231,7 @@ int emit(int L, const FillFn& fill, int max_items_per_unit, int n_streams, int32
     out[H_VERSION] = DESC_VERSION;
     out[H_L] = L;
     out[H_NRB] = nrb;
-    out[H_NKT] = nkt;
+    out[H_NKT] = nw;
     out[H_NUNITS] = (int32_t)units.size();
     out[H_NITEMS] = n_items;
     out[H_NMASKS] = (int32_t)(masks.size() / RB);
@@ -227,7 +258,7 @@ int emit(int L, const FillFn& fill, int max_items_per_unit, int n_streams, int32
         p[4] = rbinfo[(size_t)units[u].rb * 2];
         p[5] = items[(size_t)units[u].b * 2];
         p[6] = items[(size_t)units[u].b * 2 + 1];
-        p[7] = 0;
+        p[7] = rb_row0[units[u].rb];
     }
     if (n_items) std::memcpy(out + off_items, items.data(), sizeof(int32_t) * items.size());
     if (off_masks > off_items + (int64_t)n_items * 2) out[off_masks - 1] = 0;
@@ -240,7 +271,7 @@ int emit(int L, const FillFn& fill, int max_items_per_unit, int n_streams, int32
     std::vector<SchedUnit> su;
     su.reserve(units.size());
     for (const Unit& u : units)
-        su.push_back({0, u.rb, u.b, u.e, u.slot, rbinfo[(size_t)u.rb * 2], L, items.data(), off_lmasks});
+        su.push_back({0, rb_row0[u.rb], u.b, u.e, u.slot, rbinfo[(size_t)u.rb * 2], L, items.data(), off_lmasks});
     build_schedule(su, n_streams, out + off_streams, out + off_steps);
     return SDAG_OK;
 }
@@ -271,9 +302,8 @@ extern "C" int sdag_desc_build(int L, int sys_user_len, int n_docs, const int32_
         if (n_docs > 0 && nbr_off[n_docs] > 0 && !nbr_idx) return fail(SDAG_ERR_ARG, "nbr_idx is NULL");
     }
     const int nkt = (L + SDAG_KV_TILE - 1) / SDAG_KV_TILE;
-    auto fill = [&](int rb, uint64_t* bits) {
-        const int r0 = rb * SDAG_ROW_BLOCK, r1 = std::min(L, r0 + SDAG_ROW_BLOCK);
-        for (int i = r0; i < r1; ++i) {
+    auto fill = [&](int r0, int rows, uint64_t* bits) {
+        for (int i = r0; i < r0 + rows; ++i) {
             uint64_t* row = bits + (size_t)(i - r0) * nkt;
             if (i < sys_user_len || i >= qa_start) set_range(row, 0, i + 1);  // SDAG.py:107-108, 124-125
             for (int d = 0; d < n_docs; ++d) {
@@ -292,23 +322,28 @@ extern "C" int sdag_desc_build(int L, int sys_user_len, int n_docs, const int32_
             }
         }
     };
-    return emit(L, fill, max_items_per_unit, n_streams, out, cap_words, n_words);
+    // row blocks start with the prompt's segments: system text, every document (and the gap behind it), the question
+    std::vector<int> cuts = {sys_user_len, qa_start};
+    for (int d = 0; d < n_docs; ++d) {
+        cuts.push_back(spans[2 * d]);
+        cuts.push_back(spans[2 * d + 1]);
+    }
+    return emit(L, cuts, fill, max_items_per_unit, n_streams, out, cap_words, n_words);
 }
 
 extern "C" int sdag_desc_from_dense(const uint8_t* mask, int L, int max_items_per_unit, int n_streams, int32_t* out,
                                     int64_t cap_words, int64_t* n_words) {
     if (L < 0 || (L > 0 && !mask)) return fail(SDAG_ERR_ARG, "bad dense mask");
     const int nkt = (L + SDAG_KV_TILE - 1) / SDAG_KV_TILE;
-    auto fill = [&](int rb, uint64_t* bits) {
-        const int r0 = rb * SDAG_ROW_BLOCK, r1 = std::min(L, r0 + SDAG_ROW_BLOCK);
-        for (int i = r0; i < r1; ++i) {
+    auto fill = [&](int r0, int rows, uint64_t* bits) {
+        for (int i = r0; i < r0 + rows; ++i) {
             const uint8_t* src = mask + (size_t)i * L;
             uint64_t* row = bits + (size_t)(i - r0) * nkt;
             for (int j = 0; j < L; ++j)
                 if (src[j]) row[j >> 6] |= 1ull << (j & 63);
         }
     };
-    return emit(L, fill, max_items_per_unit, n_streams, out, cap_words, n_words);
+    return emit(L, {}, fill, max_items_per_unit, n_streams, out, cap_words, n_words);
 }
 
 extern "C" int sdag_desc_stats(const int32_t* d, int64_t* allowed_pairs, int32_t* n_uniform_rows,
@@ -404,7 +439,7 @@ extern "C" int sdag_batch_build(const int32_t* const* descs, int B, int n_stream
         const int32_t* d = descs[b];
         const int32_t* u = d + d[H_OFF_UNITS];
         for (int i = 0; i < d[H_NUNITS]; ++i, u += UNIT_WORDS)
-            su.push_back({b, u[0], u[1], u[2], u[3] < 0 ? -1 : slot_base[b] + u[3], u[4], d[H_L], d + d[H_OFF_ITEMS],
+            su.push_back({b, u[7], u[1], u[2], u[3] < 0 ? -1 : slot_base[b] + u[3], u[4], d[H_L], d + d[H_OFF_ITEMS],
                           (int64_t)desc_off[b] + d[H_OFF_LMASKS]});
     }
     build_schedule(su, n_streams, out + off_streams, out + off_steps);

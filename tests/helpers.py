@@ -37,20 +37,29 @@ def expand_descriptor(words):
     masks = w[w[H["OFF_MASKS"]]: w[H["OFF_MASKS"]] + 64 * w[H["NMASKS"]]].view(np.uint64).reshape(-1, 32)
     cols = np.arange(64, dtype=np.uint64)
     seen = set()
-    for rb, b, e, slot, uni, kt0, mi0, _ in units:
-        assert (kt0, mi0) == tuple(items[b])
+    nrb = int(w[H["NRB"]])
+    rbinfo = w[w[H["OFF_RBINFO"]]: w[H["OFF_RBINFO"]] + 2 * nrb].reshape(-1, 2)
+    starts = [int(x) for x in rbinfo[:, 1]] + [L]
+    assert starts[0] == 0 or nrb == 0
+    assert all(0 < b - a <= 32 for a, b in zip(starts[:-1], starts[1:]))       # the row blocks partition [0, L)
+    for rb, b, e, slot, skip, key00, mi0, row0 in units.tolist():
+        assert (key00, mi0) == tuple(items[b]) and row0 == starts[rb] and skip == rbinfo[rb][0]
+        rr = starts[rb + 1] - row0
+        assert (int(skip) & 0xffffffff) >> rr == (0xffffffff >> rr)          # rows beyond the block are skipped
         for it in range(b, e):
             assert it not in seen
             seen.add(it)
-            kt, mi = items[it]
-            r0, c0 = rb * 32, kt * 64
+            c0, mi = items[it]
+            r0 = row0
+            assert it == b or c0 >= items[it - 1][0] + 64                     # tiles of a block do not overlap
             if mi < 0:
-                assert r0 + 32 <= L and c0 + 64 <= L
-                out[r0:r0 + 32, c0:c0 + 64] = True
+                assert c0 + 64 <= L
+                out[r0:r0 + rr, c0:c0 + 64] = True
             else:
                 bits = ((masks[mi][:, None] >> cols[None, :]) & np.uint64(1)).astype(bool)
-                assert bits.any() and not bits.all()
-                rr, cc = min(32, L - r0), min(64, L - c0)
+                cc = min(64, L - c0)
+                assert bits.any() and not bits[:rr, :cc].all() if cc == 64 else bits.any()
+                assert bits[:, 0].any()                                       # a tile starts at a key some row attends
                 assert not bits[rr:].any() and not bits[:, cc:].any()
                 out[r0:r0 + rr, c0:c0 + cc] = bits[:rr, :cc]
     assert len(seen) == int(w[H["NITEMS"]])
@@ -88,7 +97,7 @@ def check_schedule(words, steps_off, streams_off, n_streams, units_of, base_of=N
             d, doff = units_of(int(b))
             units = d[d[H["OFF_UNITS"]]: d[H["OFF_UNITS"]] + 8 * d[H["NUNITS"]]].reshape(-1, 8)
             items = d[d[H["OFF_ITEMS"]]: d[H["OFF_ITEMS"]] + 2 * d[H["NITEMS"]]].reshape(-1, 2)
-            cand = [u for u in units if u[0] == rb and items[u[1]][0] == kt]
+            cand = [u for u in units if u[7] == rb and items[u[1]][0] == kt]
             assert len(cand) == 1
             u = cand[0]
             key = (int(b), int(u[1]))
@@ -97,7 +106,7 @@ def check_schedule(words, steps_off, streams_off, n_streams, units_of, base_of=N
             n = int(u[2] - u[1])
             for j in range(n):
                 st = steps[i + j]
-                assert st[0] == items[u[1] + j][0] and st[3] == b and st[4] == d[H["L"]] and st[5] == rb
+                assert st[0] == items[u[1] + j][0] and st[3] == b and st[4] == d[H["L"]] and st[5] == rb == u[7]
                 assert st[7] == u[4]
                 assert (st[2] & 1) == (j == 0) and bool(st[2] & 2) == (j == n - 1)
                 mi = items[u[1] + j][1]

@@ -37,12 +37,33 @@ def test_unit_structure():
         split = w[w[H["OFF_SPLIT"]]: w[H["OFF_SPLIT"]] + 4 * w[H["NSPLIT"]]].reshape(-1, 4)
         slots = sorted(int(s) for s in units[:, 3] if s >= 0)
         assert slots == list(range(int(w[H["NSLOTS"]])))                  # every partial slot used once
-        for rb, first, n, _ in split:
-            mine = units[(units[:, 0] == rb)]
-            assert len(mine) == n and sorted(mine[:, 3]) == list(range(first, first + n))
+        for row0, first, n, rows in split:
+            mine = units[(units[:, 7] == row0)]
+            assert len(mine) == n and sorted(mine[:, 3]) == list(range(first, first + n)) and 0 < rows <= 32
         uni = w[w[H["OFF_UNIFORM"]]: w[H["OFF_UNIFORM"]] + w[H["NUNIFORM"]]]
         assert list(uni) == [s[1] for s in spans]                          # the separator after each document
         assert np.array_equal(expand_descriptor(w), expand_descriptor(sdag_amd.from_spans(L, 60, spans, qa, None).host))
+
+
+def test_tiles_follow_the_documents():
+    """Row blocks start with the segments of the prompt and key tiles with the first key a block may attend: fewer
+    tiles than a grid aligned to multiples of 32 rows / 64 keys (516 for this layout), same relation."""
+    import sdag_amd
+    from oracle import sdag_ref
+
+    spans, qa, L = synthetic_layout(60, [300] * 10, 1, 30)
+    d = sdag_amd.from_spans(L, 60, spans, qa, None)
+    w = d.host
+    rbinfo = w[w[H["OFF_RBINFO"]]: w[H["OFF_RBINFO"]] + 2 * w[H["NRB"]]].reshape(-1, 2)
+    starts = set(int(x) for x in rbinfo[:, 1])
+    assert {0, 60, qa} | {s for s, _ in spans} | {e for _, e in spans} <= starts
+    assert d.n_items == 451
+    assert np.array_equal(expand_descriptor(w), sdag_ref.mask_from_spans(L, 60, spans, qa, None))
+    # a mask given as a dense array has no segments: blocks of 32 rows from row 0
+    dd = sdag_amd.from_dense(sdag_ref.mask_from_spans(L, 60, spans, qa, None))
+    rb2 = dd.host[dd.host[H["OFF_RBINFO"]]: dd.host[H["OFF_RBINFO"]] + 2 * dd.host[H["NRB"]]].reshape(-1, 2)
+    assert list(rb2[:, 1]) == list(range(0, L, 32))
+    assert np.array_equal(expand_descriptor(dd.host), expand_descriptor(w))
 
 
 def test_from_dense_round_trip_arbitrary_masks():

@@ -132,7 +132,31 @@ if __name__ == "__main__":
         # the bench's attention launch: 32 queries of cfg 3, one descriptor each, 4 rotating sets of tensors (8 GB)
         spans, qa, L = layout(60, 10, 300, 1, 30)
         B = 32
-        bd = sdag_amd.BatchDescriptor([sdag_amd.from_spans(L, 60, spans, qa, None, max_items_per_unit=64) for _ in range(B)])
+        Ts = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [64]
+        NS = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
+        tens = []
+        for i in range(4):
+            q = torch.randn((B, L, 32, 128), device=dev).to(torch.bfloat16).transpose(1, 2)
+            kb_ = 1 if "sharedkv" in sys.argv else B   # diagnostic: every sequence reads the same K/V memory
+            k = torch.randn((kb_, L, 8, 128), device=dev).to(torch.bfloat16).transpose(1, 2).expand(B, 8, L, 128)
+            v = torch.randn((kb_, L, 8, 128), device=dev).to(torch.bfloat16).transpose(1, 2).expand(B, 8, L, 128)
+            o = torch.empty((B, L, 32, 128), device=dev, dtype=torch.bfloat16)
+            tens.append((q, k, v, o))
+        for T in Ts:
+          for ns in NS:
+            bd = sdag_amd.BatchDescriptor([sdag_amd.from_spans(L, 60, spans, qa, None, max_items_per_unit=T) for _ in range(B)], n_streams=ns)
+            calls = [sdag_amd.BoundBatchAttention(q, k, v, bd, o) for q, k, v, o in tens]
+            for c in calls: c()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 8
+            e0.record()
+            for r in range(reps):
+                for c in calls: c()
+            e1.record(); torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) * 1e3 / (reps * len(calls))
+            print(f"cfg3 B=32 T={T} streams={ns}: {t:.1f} us/launch = {t / B:.2f} us/query-layer", flush=True)
+        sys.exit(0)
         calls = []
         for i in range(4):
             q = torch.randn((B, L, 32, 128), device=dev).to(torch.bfloat16).transpose(1, 2)
