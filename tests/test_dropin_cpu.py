@@ -281,3 +281,59 @@ def test_overlay_on_reference_tree_when_present():
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().splitlines()
     assert lines[0].startswith(pkg) and lines[1].startswith(pkg) and lines[2].startswith(ref) and lines[3] == "True"
+
+
+def _tie_groups(scores, payload):
+    """[(score, sorted payloads with that score)] in ranking order."""
+    out = []
+    for s, p in zip(scores, payload):
+        if out and out[-1][0] == s:
+            out[-1][1].append(p)
+        else:
+            out.append((s, [p]))
+    return [(s, sorted(map(repr, ps))) for s, ps in out]
+
+
+def test_hybrid_rrf_fusion_matches_reference_outputs():
+    """Fixtures produced by the reference's hybrid.py (tests/golden/make_golden_hybrid.py): scores identical float
+    for float; documents identical per group of equal score (inside such a group the reference's own order depends
+    on string hashing); this implementation orders a group by first appearance, sparse ranking first."""
+    import random
+
+    hyb = importlib.import_module("src.pipeline.retrieval.hybrid")
+    with open(f"{GOLDEN}/hybrid.json") as f:
+        g = json.load(f)
+    for c in g["one"]:
+        docs, ids, scores = hyb.rrf_fuse_one_query(c["sparse_docs"], c["sparse_ids"], c["dense_docs"], c["dense_ids"], k0=c["k0"])
+        assert scores == c["scores"]
+        assert _tie_groups(scores, zip(docs, ids)) == _tie_groups(c["scores"], zip(c["docs"], c["ids"]))
+        first_seen = {}
+        for t, i in list(zip(c["sparse_docs"], c["sparse_ids"])) + list(zip(c["dense_docs"], c["dense_ids"])):
+            first_seen.setdefault(t if i in ("", "NA") else i, len(first_seen))
+        order = [first_seen[t if i in ("", "NA") else i] for t, i in zip(docs, ids)]
+        for a in range(len(order) - 1):
+            assert scores[a] > scores[a + 1] or order[a] < order[a + 1]
+    for c in g["batch"]:
+        t, i, s = hyb.fuse_sparse_and_dense_batch(c["sparse_texts"], c["sparse_ids"], c["dense_texts"], c["dense_ids"],
+                                                  top_k=c["top_k"], seed=c["seed"])
+        assert s == c["scores"] and [len(x) for x in t] == [len(x) for x in c["texts"]]
+        for q in range(len(s)):
+            mine, ref = _tie_groups(s[q], zip(t[q], i[q])), _tie_groups(c["scores"][q], zip(c["texts"][q], c["ids"][q]))
+            assert mine[:-1] == ref[:-1]              # the last group may be cut differently by the top_k limit
+    for c in g["splits"]:
+        r = random.Random(c["seed"])
+        assert [list(hyb.split_k_between_sparse_and_dense(c["top_k"], r)) for _ in range(6)] == c["out"]
+
+    class Fixed(hyb.Retriever):
+        def __init__(self, tag):
+            self.tag = tag
+
+        def retrieve_batch(self, queries, k, bs):
+            from sdag_amd.datamodels import RetrievalBatch
+
+            return RetrievalBatch(q_embs=[self.tag] * len(queries), docs_texts_full=[[f"{self.tag}{j}" for j in range(k)] for _ in queries],
+                                  ids_full=[[f"{self.tag}{j}" for j in range(k)] for _ in queries], scores_full=[[0.0] * k for _ in queries])
+
+    rb = hyb.HybridRetriever(Fixed("d"), Fixed("s"), seed=3).retrieve_batch(["q1", "q2"], 5, 8)
+    assert rb.q_embs == ["d", "d"] and all(len(x) == 5 for x in rb.ids_full)
+    assert rb.ids_full[0][0] == "s0" and rb.ids_full[0][1] == "d0"      # equal scores: sparse ranking first
