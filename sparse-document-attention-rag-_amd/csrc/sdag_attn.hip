@@ -26,10 +26,6 @@
 
 #include "common.h"
 
-#ifndef SDAG_ABLATE
-#define SDAG_ABLATE 0
-#endif
-
 namespace sdag {
 #ifdef SDAG_STAMPS
 __device__ unsigned long long g_stamps[16];
@@ -397,7 +393,6 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
 
         STAMP(0);
         // ---- S^T = K Q^T : two 32-key blocks on top of the accumulators prepared from the mask.
-#if !(SDAG_ABLATE & 2)
         {
             bf16x8 ka[8], kb2[8];
 #define SDAG_K_READ(KS_)                                                                                      \
@@ -432,9 +427,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
             // The next step's K/V rows are requested from inside the MFMA stream (a stream's last step requests
             // its own tile again): a vector-memory instruction holds the wave's issue for about as long as three
             // MFMAs run, which is free here and a stall anywhere else.
-#if !(SDAG_ABLATE & 1)
             SDAG_STAGE_LOADS(nxt[S_B] + bg, nxt[S_KEY0], nxt[S_L], bufc ^ 1);
-#endif
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 ds_read (6 more ran ahead of the first products)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -449,10 +442,6 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
             }
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
-#else
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { s0[i] += __builtin_bit_cast(float, (unsigned)qf[i & 7][0] << 16) ; s1[i] += (float)i; }
-#endif
         STAMP(1);
         // The unit's last product is issued: its Q registers are free for the next unit's rows.
         if (last && has_next) load_q(nxt[S_B] + bg, nxt[S_ROW0], nxt[S_L]);
@@ -492,13 +481,8 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         const float nb = (float)ve - m_safe * c;  // probabilities carry 2^ve when V was scaled by 2^-ve
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-#if !(SDAG_ABLATE & 8)
             s0[i] = fast_exp2(__builtin_fmaf(s0[i], c, nb));
             s1[i] = fast_exp2(__builtin_fmaf(s1[i], c, nb));
-#else
-            s0[i] = __builtin_fmaf(s0[i], c, nb);
-            s1[i] = __builtin_fmaf(s1[i], c, nb);
-#endif
         }
 
         // ---- P^T fragments in fp16: registers 8 s .. 8 s + 7 of block kb are k-step (kb, s) of the B operand.
@@ -545,7 +529,6 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         // the MFMA that consumes them, and every group carries one sixteenth of the staging work (the rows
         // requested above are converted and written to the other tile buffer; nobody reads that buffer before the
         // barrier below).  The scheduling barriers keep the compiler from regrouping the reads behind the MFMAs.
-#if !(SDAG_ABLATE & 4)
         {
             s16x4 va[4][2];
 #define SDAG_PV_READ(I_)                                                                                      \
@@ -558,16 +541,13 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     }
             SDAG_PV_READ(0);
             SDAG_PV_READ(1);
-#if !(SDAG_ABLATE & 1)
             unsigned char* vd = smem + (2 + (bufc ^ 1)) * TILE_BYTES + st_off;
             u32x4 hv;
             vmax = 0.f;
-#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 if (i + 2 < 16) SDAG_PV_READ(i + 2);
-#if !(SDAG_ABLATE & 1)
                 {
                     const int li_ = i >> 2, lj_ = i & 3;
                     const unsigned w = vreg[li_][lj_];
@@ -576,7 +556,6 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
                     hv[lj_] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(f0, f1));
                     if (lj_ == 3) *reinterpret_cast<u32x4*>(vd + li_ * 16 * 256) = hv;
                 }
-#endif
                 {
                     union { s16x4 hlf[2]; f16x8 full; } u;
                     u.hlf[0] = va[i & 3][0];
@@ -587,12 +566,6 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
             }
 #undef SDAG_PV_READ
         }
-#else
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) asm volatile("" ::"v"(pf[kb][s]));
-#endif
 
         STAMP(4);
         asm volatile("" ::"s"(touch0), "s"(touch1), "s"(touch2), "s"(touch3));
