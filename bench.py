@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--corpus-n", type=int, default=CFG["corpus_n"])
     ap.add_argument("--mode", choices=("batched", "per_query"), default="batched")
     ap.add_argument("--no-probe", action="store_true", help="skip the extra B=1 calls timed after the run (for profiling)")
+    ap.add_argument("--exact-scan", action="store_true", help="retrieval scans the fp32 corpus (no bf16 candidate stage)")
     ap.add_argument("--attn-batch", type=int, default=CFG["batch"], help="queries per attention launch in batched mode (divides 32)")
     args = ap.parse_args()
     cfg = dict(CFG, corpus_n=args.corpus_n)
@@ -179,7 +180,7 @@ def main():
         pq_sets = [make_set(1, 1000 * rank + i) for i in range(nl)]
     pq_calls = [sdag_amd.BoundAttention(q_, k_, v_, desc, o_) for q_, k_, v_, o_ in pq_sets]
     corpus = make_corpus(cfg["corpus_n"], cfg["dim"], dev, seed=0)
-    index = sdag_amd.FlatIPIndex(cfg["dim"], device=dev)
+    index = sdag_amd.FlatIPIndex(cfg["dim"], device=dev, two_stage=not args.exact_scan)
     index._corpus = corpus  # already resident; add() would copy
     gq = torch.Generator(device=dev).manual_seed(77 + rank)
     Q = torch.randn((cfg["batch"], cfg["dim"]), generator=gq, device=dev, dtype=torch.float32)
@@ -265,7 +266,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16 attention (fp32 softmax/accumulate) + f32 retrieval",
+        "dtype": "bf16 attention (fp32 softmax/accumulate) + f32 retrieval scores (bf16 candidate scan)" if index.two_stage else "bf16 attention (fp32 softmax/accumulate) + f32 retrieval",
         "data": "synthetic",
         "config": {"workload": f"cfg2+cfg3: dense top-{cfg['top_k']} over {cfg['corpus_n']}x{cfg['dim']} f32 corpus + SDAG "
                                f"attention 32 layers x (Hq32,Hkv8,D128) L={L} (10 docs x 300 tok, no neighbours), "
@@ -273,7 +274,9 @@ def main():
                    "parallelism": f"dp{world} over queries, corpus replicated"},
         "stage": {"retrieval_ms_per_batch": t_retr / args.steps * 1e3, "sdag_ms_per_query": t_sdag / (args.steps * cfg["batch"]) * 1e3,
                   "retrieval_qps": args.steps * cfg["batch"] / t_retr, "sdag_qps": args.steps * cfg["batch"] / t_sdag,
-                  "retrieval_hbm_frac": (cfg["corpus_n"] * cfg["dim"] * 4 / (t_retr / args.steps)) / HBM_PEAK,
+                  # bytes of the corpus copy the search scans: bf16 for the two-stage search, fp32 for the plain scan
+                  "retrieval_scan": "bf16 candidates + exact fp32 rescoring" if index.two_stage else "fp32",
+                  "retrieval_hbm_frac": (cfg["corpus_n"] * cfg["dim"] * (2 if index.two_stage else 4) / (t_retr / args.steps)) / HBM_PEAK,
                   "sdag_mfma_frac": flops_per_launch / per_launch / BF16_PEAK,
                   "sdag_per_query_call_us": None if pq_us != pq_us else pq_us,
                   "sdag_per_query_call_qps": None if pq_us != pq_us else 1e6 / (pq_us * nl)},

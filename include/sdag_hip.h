@@ -154,7 +154,7 @@ int sdag_decode_attn(const void* q, const void* k, const void* v, void* o,
  *   order       = (score descending, id ascending); NaN scores are never returned
  *   fill        = (score -FLT_MAX, id -1) when fewer than k rows exist
  *
- * Q [nq, d] fp32 row-major (device), C [N, d] fp32 row-major (device), d a multiple of 32, 1 <= k <= 64.
+ * Q [nq, d] fp32 row-major (device), C [N, d] fp32 row-major (device), d a multiple of 32, 1 <= k <= 32.
  * out_s [nq, k] fp32 and out_i [nq, k] int64 on the device; ids are id_base + row.
  * workspace: at least sdag_dense_workspace_bytes(nq, N, d, k) bytes of device scratch.
  */
@@ -163,6 +163,27 @@ int64_t sdag_dense_workspace_bytes(int nq, int64_t N, int d, int k);
 int sdag_dense_topk(const float* Q, int nq, const float* C, int64_t N, int d, int k,
                     float* out_s, int64_t* out_i, int64_t id_base,
                     void* workspace, int64_t workspace_bytes, void* stream);
+
+/* The same search, same results bit for bit, in two stages that read half the bytes: a scan over a bf16 copy of
+ * the corpus picks candidates (every row whose approximate score is within a proven error bound of the k-th best),
+ * which are then scored with the exact fp32 chain and ranked.  When the candidate set cannot be vouched for (more
+ * candidates than the kernels hold), the exact scan of sdag_dense_topk runs instead, decided on the device.
+ * Replaces the same reference call as sdag_dense_topk (dense.py:82-84).
+ *
+ * sdag_corpus_to_bf16: C16 [N, d] (bf16, round to nearest even) and *max_row_norm (device float: an upper bound of
+ * the largest row norm of C) from C [N, d]; d a multiple of 4.  Called once per corpus.
+ * sdag_dense_topk2: d a multiple of 64, 1 <= k <= 32; values of Q and C finite. */
+int sdag_corpus_to_bf16(const float* C, int64_t N, int d, void* C16, float* max_row_norm, void* stream);
+
+int64_t sdag_dense_topk2_workspace_bytes(int nq, int64_t N, int d, int k);
+
+/* Diagnostics: byte offset inside the workspace of an int that is non-zero after a call whose last batch of up to 32
+ * queries was answered by the exact scan instead of the rescoring kernel. */
+int64_t sdag_dense_topk2_flag_offset(int nq, int64_t N, int d, int k);
+
+int sdag_dense_topk2(const float* Q, int nq, const float* C, const void* C16, const float* max_row_norm, int64_t N,
+                     int d, int k, float* out_s, int64_t* out_i, int64_t id_base,
+                     void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Merge n_parts partial result lists (each [nq, k], as written by sdag_dense_topk on one corpus
  * shard, e.g. after an all-gather) into the global best k per query, same ordering rule.

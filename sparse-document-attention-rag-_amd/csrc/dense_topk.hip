@@ -32,13 +32,15 @@ namespace {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 #define SDAG_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define SDAG_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
 constexpr int QT = 32;                      // queries per pass
 constexpr int TR = 128;                     // corpus rows per tile
-constexpr int KC = 32;                      // dimensions per stage
+constexpr int KC = 32;                      // fp32 dimensions per stage (128 bytes of a row)
+constexpr int KC16 = 64;                    // bf16 dimensions per stage (the same 128 bytes)
 constexpr int NST = 3;                      // LDS ring depth
 constexpr int C_STAGE = TR * KC * 4;        // 16 KiB
 constexpr int Q_STAGE = QT * KC * 4;        // 4 KiB
@@ -96,9 +98,19 @@ __device__ __forceinline__ void compact_list(unsigned char* smem, int j, int k, 
     if (lane == 0) cnt[j] = n < k ? n : k;
 }
 
-__global__ __launch_bounds__(256, 2) void dense_scan(const float* __restrict__ Q, int nq, const float* __restrict__ C,
+// BF16 = false: the exact scan described above.  BF16 = true: the same walk over bf16 copies of corpus and queries
+// (64 dimensions per 128-byte stage, one v_mfma_f32_32x32x16_bf16 per 16 dimensions): approximate scores, used only
+// to pick candidates for exact rescoring.  run_flag (optional): the kernel does nothing when *run_flag == 0.
+template <bool BF16>
+__global__ __launch_bounds__(256, 2) void dense_scan(const void* __restrict__ Qv, int nq, const void* __restrict__ Cv,
                                                      int64_t N, int d, int k, int rows_per_wg,
-                                                     float* __restrict__ part_s, int* __restrict__ part_i) {
+                                                     float* __restrict__ part_s, int* __restrict__ part_i,
+                                                     const int* __restrict__ run_flag) {
+    if (run_flag && *run_flag == 0) return;
+    constexpr int KCE = BF16 ? KC16 : KC;  // elements per stage
+    constexpr int ES = BF16 ? 2 : 4;       // bytes per element
+    const unsigned char* Q = reinterpret_cast<const unsigned char*>(Qv);
+    const unsigned char* C = reinterpret_cast<const unsigned char*>(Cv);
     // Dynamic LDS on purpose: the ring is filled only by LDS-DMA, which the optimiser does not see as a store, so
     // a static array would look never-written and its loads would be folded away.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -107,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void dense_scan(const float* __restrict__ Q
     const int64_t wg_row0 = (int64_t)blockIdx.x * rows_per_wg;
     const int64_t wg_rows = min((int64_t)rows_per_wg, N - wg_row0);
     const int ntile = (int)((wg_rows + TR - 1) / TR);
-    const int nkc = d / KC;
+    const int nkc = d / KCE;
     const int S = ntile * nkc;
 
     if (tid < QT) {
@@ -131,14 +143,14 @@ __global__ __launch_bounds__(256, 2) void dense_scan(const float* __restrict__ Q
             int64_t row = trow0 + rl;
             row = row < N ? row : N - 1;
             const int csrc = dc ^ ((rl >> 1) & 7);
-            const float* src = C + row * d + kc * KC + csrc * 4;
+            const unsigned char* src = C + (row * d + kc * KCE) * ES + csrc * 16;
             __builtin_amdgcn_global_load_lds(SDAG_GLB_PTR(src), SDAG_LDS_PTR(sb + (w * 4 + n) * 1024), 16, 0, 0);
         }
         {
             int j = w * 8 + dr;
             const int csrc = dc ^ ((j >> 1) & 7);
             j = j < nq ? j : nq - 1;
-            const float* src = Q + (int64_t)j * d + kc * KC + csrc * 4;
+            const unsigned char* src = Q + ((int64_t)j * d + kc * KCE) * ES + csrc * 16;
             __builtin_amdgcn_global_load_lds(SDAG_GLB_PTR(src), SDAG_LDS_PTR(sb + C_STAGE + w * 1024), 16, 0, 0);
         }
     };
@@ -163,21 +175,28 @@ __global__ __launch_bounds__(256, 2) void dense_scan(const float* __restrict__ Q
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int ch = ((2 * m + h) ^ swz) << 4;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(sb + a_off + ch);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(sb + b_off + ch);
-            // Lane half 0 holds dimensions 8m..8m+3, half 1 holds 8m+4..8m+7.  Swapping the upper half of
-            // register 0 with the lower half of register 1 (and 2 with 3) leaves register 0 = (8m, 8m+1),
-            // register 2 = (8m+2, 8m+3), register 1 = (8m+4, 8m+5), register 3 = (8m+6, 8m+7) across the
-            // two halves: the MFMA operand layout, in dimension order.
-            float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
-            swap_halves(a0, a1);
-            swap_halves(a2, a3);
-            swap_halves(b0, b1);
-            swap_halves(b2, b3);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc, 0, 0, 0);
+            if constexpr (BF16) {
+                // 16-byte chunk 2 m + h of a row = dimensions 16 m + 8 h .. + 7 of the stage: the MFMA operand as it is
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sb + a_off + ch);
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(sb + b_off + ch);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            } else {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(sb + a_off + ch);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(sb + b_off + ch);
+                // Lane half 0 holds dimensions 8m..8m+3, half 1 holds 8m+4..8m+7.  Swapping the upper half of
+                // register 0 with the lower half of register 1 (and 2 with 3) leaves register 0 = (8m, 8m+1),
+                // register 2 = (8m+2, 8m+3), register 1 = (8m+4, 8m+5), register 3 = (8m+6, 8m+7) across the
+                // two halves: the MFMA operand layout, in dimension order.
+                float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+                swap_halves(a0, a1);
+                swap_halves(a2, a3);
+                swap_halves(b0, b1);
+                swap_halves(b2, b3);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc, 0, 0, 0);
+            }
         }
         if (++kc < nkc) continue;
         kc = 0;
@@ -267,7 +286,9 @@ constexpr int MRG_WAVES = MRG_THREADS / 64;
 template <typename IdT>
 __global__ __launch_bounds__(MRG_THREADS) void topk_merge_kernel(const float* __restrict__ in_s, const IdT* __restrict__ in_i,
                                                          int n_parts, int nq, int q_stride, int k, int64_t id_base,
-                                                         float* __restrict__ out_s, int64_t* __restrict__ out_i) {
+                                                         float* __restrict__ out_s, int64_t* __restrict__ out_i,
+                                                         const int* __restrict__ run_flag) {
+    if (run_flag && *run_flag == 0) return;  // nothing to do (see sdag_dense_topk2)
     __shared__ float a_s[MRG_A];
     __shared__ int64_t a_i[MRG_A];
     __shared__ float b_s[MRG_B];
@@ -317,6 +338,154 @@ __global__ __launch_bounds__(MRG_THREADS) void topk_merge_kernel(const float* __
         out_s[(int64_t)q * k + tid] = id < 0 ? -FLT_MAX : fs[tid];
         out_i[(int64_t)q * k + tid] = id < 0 ? -1 : id;
     }
+}
+
+// ---- two-stage search: bf16 candidate scan + exact rescoring ---------------------------------------------------
+// Rounding a value to bf16 (round to nearest even) changes it by at most 2^-8 of its magnitude, so for the rounded
+// copies q', c' of a query and a corpus row  |q.c - q'.c'| <= (2^-7 + 2^-16) |q| |c|  (Cauchy-Schwarz on the
+// per-dimension terms); both this approximate score and the exact one are fp32 sums of d terms, each with a rounding
+// error of at most d 2^-24 |q| |c|.  With eps = EPS_REL(d) |q| max|c| every approximate score is within eps of the
+// exact score of the same row.  Then every row of the exact top k has an approximate score >= a_k - 2 eps, a_k being
+// the k-th best approximate score: the k rows with the best approximate scores have exact scores >= a_k - eps, so the
+// k-th best exact score is at least that, and a row that reaches it exactly is within eps of it approximately.
+// The candidate scan keeps the best k approximate scores per stripe (so a_k is known exactly); all entries
+// >= a_k - 2 eps are rescored with the exact fp32 chain and ranked.  A stripe whose k-th entry is itself a candidate
+// (it may have dropped one), or more candidates than fit, raise a flag, and the exact scan then runs for the batch (the flag is read on the device: no host round trip).
+constexpr int RS_CMAX = 512;  // candidates per query the rescoring kernel holds
+constexpr int RS_DC = 128;    // dimensions per LDS chunk
+constexpr int RS_G = 64;      // candidates rescored per pass
+
+__host__ __device__ inline float eps_rel(int d) { return 0.0079f + (float)d * 1.2e-7f; }
+
+// One block per query: bf16 copy (round to nearest even) and eps = eps_rel(d) * |q| * cmax, rounded up.
+__global__ __launch_bounds__(256) void query_prepare_kernel(const float* __restrict__ Q, int d, const float* __restrict__ cmax,
+                                                            unsigned short* __restrict__ Q16, float* __restrict__ eps) {
+    __shared__ float red[256];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    float ss = 0.f;
+    for (int j = tid; j < d; j += 256) {
+        const float x = Q[(int64_t)q * d + j];
+        ss = __builtin_fmaf(x, x, ss);
+        Q16[(int64_t)q * d + j] = __builtin_bit_cast(unsigned short, (__bf16)x);
+    }
+    red[tid] = ss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) eps[q] = eps_rel(d) * sqrtf(red[0]) * cmax[0] * 1.001f + 1e-30f;
+}
+
+// bf16 copy of corpus rows and the largest row norm (as float bits: norms are non-negative, so integer order =
+// float order).  One wave per row.
+__global__ __launch_bounds__(256) void corpus_prepare_kernel(const float* __restrict__ C, int64_t N, int d,
+                                                             unsigned short* __restrict__ C16, unsigned* __restrict__ max_norm_bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    float ss = 0.f;
+    for (int j = lane * 4; j < d; j += 256) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(C + row * d + j);
+        ss = __builtin_fmaf(x[0], x[0], ss);
+        ss = __builtin_fmaf(x[1], x[1], ss);
+        ss = __builtin_fmaf(x[2], x[2], ss);
+        ss = __builtin_fmaf(x[3], x[3], ss);
+        ushort4 o;
+        o.x = __builtin_bit_cast(unsigned short, (__bf16)x[0]);
+        o.y = __builtin_bit_cast(unsigned short, (__bf16)x[1]);
+        o.z = __builtin_bit_cast(unsigned short, (__bf16)x[2]);
+        o.w = __builtin_bit_cast(unsigned short, (__bf16)x[3]);
+        *reinterpret_cast<ushort4*>(C16 + row * d + j) = o;
+    }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) atomicMax(max_norm_bits, __float_as_uint(sqrtf(ss) * 1.0001f));
+}
+
+// One block per query: collect the candidates, rescore them with the exact chain, write the best k.
+__global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ Q, const float* __restrict__ C, int d, int k,
+                                                      const float* __restrict__ part_s, const int* __restrict__ part_i, int n_wg,
+                                                      const float* __restrict__ approx_s, const float* __restrict__ eps,
+                                                      int64_t id_base, float* __restrict__ out_s, int64_t* __restrict__ out_i,
+                                                      int* __restrict__ flag) {
+    __shared__ int cand[RS_CMAX];
+    __shared__ float ex[RS_CMAX];
+    __shared__ float rows[RS_G][RS_DC + 1];
+    __shared__ float qs[RS_DC];
+    __shared__ int n_s, bad_s;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) { n_s = 0; bad_s = 0; }
+    __syncthreads();
+    const float ak = approx_s[(int64_t)q * k + (k - 1)];
+    const float thr = ak == -FLT_MAX ? -INFINITY : ak - 2.0f * eps[q];   // fewer than k rows in all: take everything
+    for (int e = tid; e < n_wg * k; e += 256) {
+        const int part = e / k, t = e - part * k;
+        const int64_t src = ((int64_t)part * QT + q) * k + t;
+        const int id = part_i[src];
+        if (id < 0 || !(part_s[src] >= thr)) continue;
+        if (t == k - 1) bad_s = 1;  // the stripe's list is full of candidates: it may have dropped one
+        const int pos = atomicAdd(&n_s, 1);
+        if (pos < RS_CMAX) cand[pos] = id;
+    }
+    __syncthreads();
+    int n = n_s;
+    if (n > RS_CMAX) {
+        n = RS_CMAX;
+        if (tid == 0) bad_s = 1;
+    }
+    // ---- exact scores: thread t < RS_G owns candidate g0 + t.  Rows and the query pass through LDS in chunks of
+    // RS_DC dimensions; the next chunk's pieces are already in flight (in registers) while a chunk is consumed.
+    // Dimensions past d are staged as zeros: fma(0, 0, acc) leaves the chain's value unchanged.
+    constexpr int PIECES = RS_G * (RS_DC / 4) / 256;  // float4 pieces per thread and chunk
+    for (int g0 = 0; g0 < n; g0 += RS_G) {
+        float acc = 0.f;
+        f32x4 pre[PIECES];
+        float preq = 0.f;
+        auto fetch = [&](int dc) {
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int e = tid + 256 * i;
+                const int rr = e / (RS_DC / 4), c4 = e - rr * (RS_DC / 4);
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                pre[i] = (g0 + rr < n && dc + 4 * c4 < d) ? *reinterpret_cast<const f32x4*>(C + (int64_t)cand[g0 + rr] * d + dc + 4 * c4) : zero;
+            }
+            if (tid < RS_DC) preq = dc + tid < d ? Q[(int64_t)q * d + dc + tid] : 0.f;
+        };
+        fetch(0);
+        for (int dc = 0; dc < d; dc += RS_DC) {
+            __syncthreads();  // the previous chunk has been consumed
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int e = tid + 256 * i;
+                const int rr = e / (RS_DC / 4), c4 = e - rr * (RS_DC / 4);
+                rows[rr][4 * c4] = pre[i][0]; rows[rr][4 * c4 + 1] = pre[i][1]; rows[rr][4 * c4 + 2] = pre[i][2]; rows[rr][4 * c4 + 3] = pre[i][3];
+            }
+            if (tid < RS_DC) qs[tid] = preq;
+            __syncthreads();
+            if (dc + RS_DC < d) fetch(dc + RS_DC);
+            if (tid < RS_G && g0 + tid < n) {
+#pragma unroll 32
+                for (int j = 0; j < RS_DC; ++j) acc = __builtin_fmaf(rows[tid][j], qs[j], acc);
+            }
+        }
+        if (tid < RS_G && g0 + tid < n) ex[g0 + tid] = acc;
+    }
+    __syncthreads();
+    for (int c = tid; c < n; c += 256) {
+        const float sc = ex[c];
+        const int ic = cand[c];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += better(ex[j], cand[j], sc, ic) ? 1 : 0;
+        if (rank < k && sc == sc) {
+            out_s[(int64_t)q * k + rank] = sc;
+            out_i[(int64_t)q * k + rank] = (int64_t)ic + id_base;
+        }
+    }
+    if (tid < k && tid >= n) {
+        out_s[(int64_t)q * k + tid] = -FLT_MAX;
+        out_i[(int64_t)q * k + tid] = -1;
+    }
+    if (tid == 0 && bad_s) atomicOr(flag, 1);
 }
 
 // ---- small similarity ops ---------------------------------------------------------------------------
@@ -390,14 +559,117 @@ extern "C" int sdag_dense_topk(const float* Q, int nq, const float* C, int64_t N
     for (int q0 = 0; q0 < nq; q0 += QT) {
         const int nqt = nq - q0 < QT ? nq - q0 : QT;
         if (N > 0) {
-            SDAG_HIP_CHECK(hipFuncSetAttribute((const void*)dense_scan, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS));
-            hipLaunchKernelGGL(dense_scan, dim3(pl.n_wg), dim3(256), SCAN_LDS, st, Q + (int64_t)q0 * d, nqt, C, N, d, k,
-                               pl.rows_per_wg, part_s, part_i);
+            SDAG_HIP_CHECK(hipFuncSetAttribute((const void*)dense_scan<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS));
+            hipLaunchKernelGGL(dense_scan<false>, dim3(pl.n_wg), dim3(256), SCAN_LDS, st, (const void*)(Q + (int64_t)q0 * d), nqt,
+                               (const void*)C, N, d, k, pl.rows_per_wg, part_s, part_i, (const int*)nullptr);
             SDAG_HIP_CHECK(hipGetLastError());
         }
         hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, part_s, part_i, N > 0 ? pl.n_wg : 0, nqt, QT,
-                           k, id_base, out_s + (int64_t)q0 * k, out_i + (int64_t)q0 * k);
+                           k, id_base, out_s + (int64_t)q0 * k, out_i + (int64_t)q0 * k, (const int*)nullptr);
         SDAG_HIP_CHECK(hipGetLastError());
+    }
+    return SDAG_OK;
+}
+
+extern "C" int sdag_corpus_to_bf16(const float* C, int64_t N, int d, void* C16, float* max_row_norm, void* stream) {
+    if (N < 0 || d <= 0 || d % 4) return fail(SDAG_ERR_ARG, "bad N or d (d must be a positive multiple of 4)");
+    if (!max_row_norm || (N > 0 && (!C || !C16))) return fail(SDAG_ERR_ARG, "NULL pointer");
+    if (((uintptr_t)C | (uintptr_t)C16) & 15) return fail(SDAG_ERR_ARG, "C and C16 must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    SDAG_HIP_CHECK(hipMemsetAsync(max_row_norm, 0, sizeof(float), st));
+    if (N > 0) {
+        if ((N + 3) / 4 > 0x7fffffff) return fail(SDAG_ERR_ARG, "N too large");
+        hipLaunchKernelGGL(corpus_prepare_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, C, N, d, (unsigned short*)C16,
+                           (unsigned*)max_row_norm);
+        SDAG_HIP_CHECK(hipGetLastError());
+    }
+    return SDAG_OK;
+}
+
+namespace {
+struct Ws2 { int64_t part_s, part_i, approx_s, approx_i, flag, eps, q16, exact, total; };
+Ws2 plan_ws2(int nq, int64_t N, int d, int k) {
+    const ScanPlan pl = plan_scan(N);
+    Ws2 w;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { const int64_t o = off; off += (bytes + 255) & ~255ll; return o; };
+    w.part_s = take((int64_t)pl.n_wg * QT * k * 4);
+    w.part_i = take((int64_t)pl.n_wg * QT * k * 4);
+    w.approx_s = take((int64_t)QT * k * 4);
+    w.approx_i = take((int64_t)QT * k * 8);
+    w.flag = take(4);
+    w.eps = take((int64_t)nq * 4);
+    w.q16 = take((int64_t)nq * d * 2);
+    w.exact = take((int64_t)pl.n_wg * QT * k * 8);
+    w.total = off;
+    return w;
+}
+}  // namespace
+
+extern "C" int64_t sdag_dense_topk2_workspace_bytes(int nq, int64_t N, int d, int k) {
+    if (k <= 0 || k > MAX_K || N < 0 || nq < 0 || d <= 0) return -1;
+    return plan_ws2(nq, N, d, k).total;
+}
+
+extern "C" int64_t sdag_dense_topk2_flag_offset(int nq, int64_t N, int d, int k) {
+    if (k <= 0 || k > MAX_K || N < 0 || nq < 0 || d <= 0) return -1;
+    return plan_ws2(nq, N, d, k).flag;
+}
+
+extern "C" int sdag_dense_topk2(const float* Q, int nq, const float* C, const void* C16, const float* max_row_norm, int64_t N,
+                                int d, int k, float* out_s, int64_t* out_i, int64_t id_base, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
+    if (nq < 0 || N < 0) return fail(SDAG_ERR_ARG, "negative nq or N");
+    if (d <= 0 || d % KC16) return fail(SDAG_ERR_ARG, "d=%d must be a positive multiple of %d", d, KC16);
+    if (k <= 0 || k > MAX_K) return fail(SDAG_ERR_ARG, "k=%d outside [1, %d]", k, MAX_K);
+    if (N > INT_MAX) return fail(SDAG_ERR_ARG, "N too large for one shard");
+    if (nq == 0) return SDAG_OK;
+    if (!Q || !out_s || !out_i || !max_row_norm || (N > 0 && (!C || !C16))) return fail(SDAG_ERR_ARG, "NULL pointer");
+    if (((uintptr_t)Q | (uintptr_t)C | (uintptr_t)C16) & 15) return fail(SDAG_ERR_ARG, "Q, C and C16 must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const ScanPlan pl = plan_scan(N);
+    const Ws2 w = plan_ws2(nq, N, d, k);
+    if (!workspace || workspace_bytes < w.total) return fail(SDAG_ERR_CAPACITY, "workspace needs %lld bytes", (long long)w.total);
+    unsigned char* ws = (unsigned char*)workspace;
+    float* part_s = (float*)(ws + w.part_s);
+    int* part_i = (int*)(ws + w.part_i);
+    float* approx_s = (float*)(ws + w.approx_s);
+    int64_t* approx_i = (int64_t*)(ws + w.approx_i);
+    int* flag = (int*)(ws + w.flag);
+    float* eps = (float*)(ws + w.eps);
+    unsigned short* q16 = (unsigned short*)(ws + w.q16);
+    float* ex_s = (float*)(ws + w.exact);
+    int* ex_i = (int*)(ex_s + (int64_t)pl.n_wg * QT * k);
+    if ((((int64_t)pl.n_wg * k + 63) / 64) * k > MRG_A) return fail(SDAG_ERR_ARG, "too many partial lists for the merge");
+    hipLaunchKernelGGL(query_prepare_kernel, dim3(nq), dim3(256), 0, st, Q, d, max_row_norm, q16, eps);
+    SDAG_HIP_CHECK(hipGetLastError());
+    SDAG_HIP_CHECK(hipFuncSetAttribute((const void*)dense_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS));
+    SDAG_HIP_CHECK(hipFuncSetAttribute((const void*)dense_scan<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS));
+    for (int q0 = 0; q0 < nq; q0 += QT) {
+        const int nqt = nq - q0 < QT ? nq - q0 : QT;
+        float* os = out_s + (int64_t)q0 * k;
+        int64_t* oi = out_i + (int64_t)q0 * k;
+        SDAG_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), st));
+        if (N > 0) {
+            hipLaunchKernelGGL(dense_scan<true>, dim3(pl.n_wg), dim3(256), SCAN_LDS, st, (const void*)(q16 + (int64_t)q0 * d), nqt, C16,
+                               N, d, k, pl.rows_per_wg, part_s, part_i, (const int*)nullptr);
+            SDAG_HIP_CHECK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, part_s, part_i, N > 0 ? pl.n_wg : 0, nqt, QT, k,
+                           (int64_t)0, approx_s, approx_i, (const int*)nullptr);
+        SDAG_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(rescore_kernel, dim3(nqt), dim3(256), 0, st, Q + (int64_t)q0 * d, C, d, k, part_s, part_i, N > 0 ? pl.n_wg : 0,
+                           approx_s, eps + q0, id_base, os, oi, flag);
+        SDAG_HIP_CHECK(hipGetLastError());
+        if (N > 0) {
+            // only when the rescoring kernel could not vouch for its candidate set: the exact scan of the batch
+            hipLaunchKernelGGL(dense_scan<false>, dim3(pl.n_wg), dim3(256), SCAN_LDS, st, (const void*)(Q + (int64_t)q0 * d), nqt,
+                               (const void*)C, N, d, k, pl.rows_per_wg, ex_s, ex_i, (const int*)flag);
+            SDAG_HIP_CHECK(hipGetLastError());
+            hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, ex_s, ex_i, pl.n_wg, nqt, QT, k, id_base, os,
+                               oi, (const int*)flag);
+            SDAG_HIP_CHECK(hipGetLastError());
+        }
     }
     return SDAG_OK;
 }
@@ -410,7 +682,7 @@ extern "C" int sdag_topk_merge(const float* in_s, const int64_t* in_i, int n_par
     if (!out_s || !out_i || (n_parts > 0 && (!in_s || !in_i))) return fail(SDAG_ERR_ARG, "NULL pointer");
     if ((((int64_t)n_parts * k + 63) / 64) * k > MRG_A) return fail(SDAG_ERR_ARG, "too many partial lists");
     hipLaunchKernelGGL(topk_merge_kernel<int64_t>, dim3(nq), dim3(MRG_THREADS), 0, (hipStream_t)stream, in_s, in_i, n_parts, nq, nq, k,
-                       (int64_t)0, out_s, out_i);
+                       (int64_t)0, out_s, out_i, (const int*)nullptr);
     SDAG_HIP_CHECK(hipGetLastError());
     return SDAG_OK;
 }

@@ -48,6 +48,10 @@ SIGNATURES = {
     "sdag_dense_workspace_bytes": (i64, [i32, i64, i32, i32]),
     "sdag_dense_topk": (i32, [vp, i32, vp, i64, i32, i32, vp, vp, i64, vp, i64, vp]),
     "sdag_topk_merge": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
+    "sdag_corpus_to_bf16": (i32, [vp, i64, i32, vp, vp, vp]),
+    "sdag_dense_topk2_workspace_bytes": (i64, [i32, i64, i32, i32]),
+    "sdag_dense_topk2_flag_offset": (i64, [i32, i64, i32, i32]),
+    "sdag_dense_topk2": (i32, [vp, i32, vp, vp, vp, i64, i32, i32, vp, vp, i64, vp, i64, vp]),
     "sdag_gram": (i32, [vp, i32, i32, vp, vp]),
     "sdag_centroid_sims": (i32, [vp, i32, vp, i32, i32, vp, vp, vp]),
 }

@@ -29,9 +29,16 @@ def _as_f32_2d(x, name: str) -> np.ndarray:
 class FlatIPIndex:
     """faiss.IndexFlatIP-shaped exact search on one GPU."""
 
-    def __init__(self, d: int, device="cuda:0", id_base: int = 0):
+    def __init__(self, d: int, device="cuda:0", id_base: int = 0, two_stage: bool = True):
+        """``two_stage``: search through a bf16 copy of the corpus (built on first use, +50 % memory) followed by
+        exact rescoring of the candidates -- same results bit for bit, half the bytes scanned; needs d % 64 == 0,
+        otherwise (or with ``two_stage=False``) every search scans the fp32 corpus."""
         if d <= 0 or d % 32:
             raise ValueError("d must be a positive multiple of 32")
+        self.two_stage = bool(two_stage) and d % 64 == 0
+        self._c16: Optional[torch.Tensor] = None       # [N, d] bf16 copy of _corpus
+        self._c16_of: Optional[torch.Tensor] = None    # the tensor _c16 was made from
+        self._cmax: Optional[torch.Tensor] = None      # [1] fp32: bound of the largest row norm
         self.d = int(d)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -83,6 +90,8 @@ class FlatIPIndex:
         out_i = torch.empty((nq, kk), dtype=torch.int64, device=self.device)
         N = self.ntotal
         lib = _lib.lib()
+        if self.two_stage and N > 0:
+            return self._search_two_stage(q, nq, kk, out_s, out_i)
         need = lib.sdag_dense_workspace_bytes(nq, N, self.d, kk)
         if need < 0:
             raise _lib.SdagError(-1, "bad workspace query")
@@ -94,6 +103,37 @@ class FlatIPIndex:
                                      self.id_base, self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr(self.device))
         _lib.check(rc)
         return out_s, out_i
+
+
+    def _search_two_stage(self, q, nq, kk, out_s, out_i):
+        lib = _lib.lib()
+        N = self.ntotal
+        with torch.cuda.device(self.device):
+            if self._c16 is None or self._c16_of is not self._corpus:
+                self._c16 = torch.empty((N, self.d), dtype=torch.bfloat16, device=self.device)
+                self._cmax = torch.zeros(1, dtype=torch.float32, device=self.device)
+                _lib.check(lib.sdag_corpus_to_bf16(self._corpus.data_ptr(), N, self.d, self._c16.data_ptr(),
+                                                   self._cmax.data_ptr(), _lib.stream_ptr(self.device)))
+                self._c16_of = self._corpus
+            need = lib.sdag_dense_topk2_workspace_bytes(nq, N, self.d, kk)
+            if need < 0:
+                raise _lib.SdagError(-1, "bad workspace query")
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(max(int(need), 256), dtype=torch.uint8, device=self.device)
+            rc = lib.sdag_dense_topk2(q.data_ptr(), nq, self._corpus.data_ptr(), self._c16.data_ptr(), self._cmax.data_ptr(),
+                                      N, self.d, kk, out_s.data_ptr(), out_i.data_ptr(), self.id_base,
+                                      self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr(self.device))
+        _lib.check(rc)
+        self._last = (nq, N, kk)
+        return out_s, out_i
+
+    def last_search_fell_back(self) -> bool:
+        """Diagnostics: did the last two-stage search (its last batch of 32 queries) have to run the exact scan?"""
+        if not self.two_stage or getattr(self, "_last", None) is None:
+            return False
+        nq, N, kk = self._last
+        off = int(_lib.lib().sdag_dense_topk2_flag_offset(nq, N, self.d, kk))
+        return bool(self._ws[off:off + 4].view(torch.int32).item())
 
 
 def merge_partial_topk(parts_s: torch.Tensor, parts_i: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -89,11 +89,47 @@ def test_dense_topk_bit_exact(N, d, nq, k):
     if N >= 1000:
         C[N // 2] = C[N // 3]  # an exact tie: the lower id must come first
     rs, ri = dense_ref.dense_topk(Q, C, k, id_base=5)
-    idx = sdag_amd.FlatIPIndex(d, device=_dev(), id_base=5)
-    idx.add(C)
-    s, i = idx.search(Q, k)
-    assert np.array_equal(i, ri)
-    assert np.array_equal(s.view(np.uint32), rs.view(np.uint32))
+    for two_stage in (True, False):      # bf16 candidate scan + exact rescoring (d % 64 == 0), and the plain exact scan
+        idx = sdag_amd.FlatIPIndex(d, device=_dev(), id_base=5, two_stage=two_stage)
+        assert idx.two_stage == (two_stage and d % 64 == 0)
+        idx.add(C)
+        s, i = idx.search(Q, k)
+        assert np.array_equal(i, ri)
+        assert np.array_equal(s.view(np.uint32), rs.view(np.uint32))
+        if N >= 20000:
+            assert not idx.last_search_fell_back()   # a large ordinary corpus is answered from the candidates
+
+
+def test_two_stage_search_when_candidates_abound():
+    """Corpora built against the candidate scan: hundreds of rows within rounding distance of the best score (more
+    candidates than the rescoring kernel holds, and whole stripes full of them), exact duplicates, a corpus smaller
+    than k, and rows with wildly different norms.  Results must still equal the exact oracle bit for bit."""
+    import sdag_amd
+    from oracle import dense_ref
+
+    rng = np.random.default_rng(11)
+    d, nq, k = 128, 9, 10
+    Q = rng.standard_normal((nq, d), dtype=np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    cases = []
+    C = rng.standard_normal((6000, d), dtype=np.float32)
+    C /= np.linalg.norm(C, axis=1, keepdims=True)
+    C[100:900] = Q[0] * 0.9 + 1e-4 * rng.standard_normal((800, d), dtype=np.float32)     # 800 near-ties for query 0
+    C[2000:2040] = Q[1]                                                                  # 40 exact duplicates
+    cases.append(C)
+    cases.append(C[:6].copy())                                                           # fewer rows than k
+    C2 = rng.standard_normal((3000, d), dtype=np.float32) * np.exp(rng.uniform(-6, 6, (3000, 1))).astype(np.float32)
+    cases.append(C2)
+    fell_back = []
+    for C in cases:
+        rs, ri = dense_ref.dense_topk(Q, C, k, id_base=0)
+        idx = sdag_amd.FlatIPIndex(d, device=_dev())
+        idx.add(C)
+        s, i = idx.search(Q, k)
+        assert np.array_equal(i, ri)
+        assert np.array_equal(s.view(np.uint32), rs.view(np.uint32))
+        fell_back.append(idx.last_search_fell_back())
+    assert fell_back[0] and not fell_back[1]         # 800 near-ties: the exact scan had to answer
 
 
 def test_attention_large_values_in_v():
