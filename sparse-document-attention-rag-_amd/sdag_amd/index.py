@@ -67,6 +67,7 @@ class FlatIPIndex:
 
     def reset(self) -> None:
         self._corpus = None
+        self._c16 = self._c16_of = self._cmax = None
 
     def search(self, q, k: int) -> Tuple[np.ndarray, np.ndarray]:
         """(scores f32 [nq, k], ids i64 [nq, k]) as numpy, best first -- the faiss return order."""
@@ -105,16 +106,24 @@ class FlatIPIndex:
         return out_s, out_i
 
 
+    def prepare(self) -> None:
+        """Build what the first search would otherwise build: the bf16 copy of the corpus for the two-stage search
+        (index construction work, like ``add``; a no-op when it is up to date or the index scans fp32)."""
+        N = self.ntotal
+        if not self.two_stage or N == 0 or (self._c16 is not None and self._c16_of is self._corpus):
+            return
+        with torch.cuda.device(self.device):
+            self._c16 = torch.empty((N, self.d), dtype=torch.bfloat16, device=self.device)
+            self._cmax = torch.zeros(1, dtype=torch.float32, device=self.device)
+            _lib.check(_lib.lib().sdag_corpus_to_bf16(self._corpus.data_ptr(), N, self.d, self._c16.data_ptr(),
+                                                      self._cmax.data_ptr(), _lib.stream_ptr(self.device)))
+            self._c16_of = self._corpus
+
     def _search_two_stage(self, q, nq, kk, out_s, out_i):
         lib = _lib.lib()
         N = self.ntotal
+        self.prepare()
         with torch.cuda.device(self.device):
-            if self._c16 is None or self._c16_of is not self._corpus:
-                self._c16 = torch.empty((N, self.d), dtype=torch.bfloat16, device=self.device)
-                self._cmax = torch.zeros(1, dtype=torch.float32, device=self.device)
-                _lib.check(lib.sdag_corpus_to_bf16(self._corpus.data_ptr(), N, self.d, self._c16.data_ptr(),
-                                                   self._cmax.data_ptr(), _lib.stream_ptr(self.device)))
-                self._c16_of = self._corpus
             need = lib.sdag_dense_topk2_workspace_bytes(nq, N, self.d, kk)
             if need < 0:
                 raise _lib.SdagError(-1, "bad workspace query")
