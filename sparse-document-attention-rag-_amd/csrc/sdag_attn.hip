@@ -27,6 +27,10 @@
 #include "common.h"
 
 namespace sdag {
+#ifdef SDAG_WGTIMES
+// Diagnostic build only: per-workgroup wall time (100 MHz ticks), steps walked and start tick of the last launch.
+__device__ unsigned g_wg_ticks[8192][4];
+#endif
 #ifdef SDAG_STAMPS
 __device__ unsigned long long g_stamps[16];
 #endif
@@ -251,11 +255,14 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         const unsigned bytes = (unsigned)(L - 1) * row_bytes + (unsigned)(D * 2) - off;
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base + off), 0, (int)bytes, 0x00020000);
     };
-#define SDAG_STAGE_LOADS(B_, KEY0_, L_, BUF_)                                                                   \
+    // The two descriptors of a tile are made apart from the loads (SDAG_TILE_RSRC, with its branch on a change of
+    // sequence), so that the loads can sit in one basic block with the MFMAs they are interleaved with.
+#define SDAG_TILE_RSRC(B_, KEY0_, L_)                                                                         \
+    if ((B_) != b_kv) set_kv_base(B_);                                                                        \
+    const auto krs = tile_rsrc(kbase, (unsigned)p.k_sl * 2u, (KEY0_), (L_));                                  \
+    const auto vrs = tile_rsrc(vbase, (unsigned)p.v_sl * 2u, (KEY0_), (L_));
+#define SDAG_STAGE_LOADS(BUF_)                                                                                \
     {                                                                                                         \
-        if ((B_) != b_kv) set_kv_base(B_);                                                                    \
-        const auto krs = tile_rsrc(kbase, (unsigned)p.k_sl * 2u, (KEY0_), (L_));                   \
-        const auto vrs = tile_rsrc(vbase, (unsigned)p.v_sl * 2u, (KEY0_), (L_));                   \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
             vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff0 + i * vstep, 0, 0)); \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
@@ -356,7 +363,10 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     i32x8 nxt = steps[min(s_begin + 1, s_end - 1)];
     load_q(cur[S_B] + bg, cur[S_ROW0], cur[S_L]);
     __syncthreads();  // vtag zeroed
-    SDAG_STAGE_LOADS(cur[S_B] + bg, cur[S_KEY0], cur[S_L], 0);
+    {
+        SDAG_TILE_RSRC(cur[S_B] + bg, cur[S_KEY0], cur[S_L]);
+        SDAG_STAGE_LOADS(0);
+    }
     SDAG_STAGE_STORE(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the K pieces have landed
     stage_tag(0, 1u);
@@ -374,6 +384,9 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
 #endif
     int bufc = 0;
     unsigned seq = 1u;
+#ifdef SDAG_WGTIMES
+    const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int it = s_begin; it < s_end; ++it, ++seq) {
         const bool has_next = it + 1 < s_end;
         const i32x8 nn = steps[min(it + 2, s_end - 1)];
@@ -392,6 +405,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         const unsigned char* vb_lds = smem + (2 + bufc) * TILE_BYTES;
 
         STAMP(0);
+        SDAG_TILE_RSRC(nxt[S_B] + bg, nxt[S_KEY0], nxt[S_L]);
         // ---- S^T = K Q^T : two 32-key blocks on top of the accumulators prepared from the mask.
         {
             bf16x8 ka[8], kb2[8];
@@ -427,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
             // The next step's K/V rows are requested from inside the MFMA stream (a stream's last step requests
             // its own tile again): a vector-memory instruction holds the wave's issue for about as long as three
             // MFMAs run, which is free here and a stall anywhere else.
-            SDAG_STAGE_LOADS(nxt[S_B] + bg, nxt[S_KEY0], nxt[S_L], bufc ^ 1);
+            SDAG_STAGE_LOADS(bufc ^ 1);
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 ds_read (6 more ran ahead of the first products)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -646,6 +660,15 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         nxt = nn;
     }
 
+#ifdef SDAG_WGTIMES
+    if (tid == 0 && blockIdx.x < 8192) {
+        g_wg_ticks[blockIdx.x][0] = (unsigned)(__builtin_amdgcn_s_memrealtime() - wg_t0);
+        g_wg_ticks[blockIdx.x][1] = (unsigned)(s_end - s_begin);
+        g_wg_ticks[blockIdx.x][2] = (unsigned)(wg_t0 & 0xffffffffu);
+        // HW_ID bits 8-15 (CU, shader array, shader engine) and XCC_ID bits 0-3
+        g_wg_ticks[blockIdx.x][3] = ((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 8) & 0xffu) | ((__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu) << 8);
+    }
+#endif
 #ifdef SDAG_STAMPS
     if (blockIdx.x == 0 && tid == 0) {
         for (int i = 0; i < 8; ++i) g_stamps[i] = st_acc[i];
@@ -943,6 +966,13 @@ extern "C" int sdag_mask_materialize(const int32_t* desc_host, const int32_t* de
     return SDAG_OK;
 }
 
+#ifdef SDAG_WGTIMES
+extern "C" int sdag_debug_wg_ticks(unsigned* out) {
+    SDAG_HIP_CHECK(hipDeviceSynchronize());
+    SDAG_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(sdag::g_wg_ticks), sizeof(unsigned) * 8192 * 4));
+    return SDAG_OK;
+}
+#endif
 #ifdef SDAG_STAMPS
 extern "C" int sdag_debug_stamps(unsigned long long* out) {
     SDAG_HIP_CHECK(hipDeviceSynchronize());
