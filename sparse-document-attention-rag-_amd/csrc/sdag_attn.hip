@@ -389,7 +389,6 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
 #endif
     for (int it = s_begin; it < s_end; ++it, ++seq) {
         const bool has_next = it + 1 < s_end;
-        const i32x8 nn = steps[min(it + 2, s_end - 1)];
         const int b_cur = cur[S_B] + bg, key0_cur = cur[S_KEY0], L_cur = cur[S_L];
         const bool first = (cur[S_FLAGS] & 1) != 0, last = (cur[S_FLAGS] & 2) != 0;
         if (first) {
@@ -406,6 +405,8 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
 
         STAMP(0);
         SDAG_TILE_RSRC(nxt[S_B] + bg, nxt[S_KEY0], nxt[S_L]);
+        // The V-range tag of this tile: read first, so that it has arrived long before it is looked at.
+        const unsigned tg = vtag[bufc];
         // ---- S^T = K Q^T : two 32-key blocks on top of the accumulators prepared from the mask.
         {
             bf16x8 ka[8], kb2[8];
@@ -459,24 +460,23 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         STAMP(1);
         // The unit's last product is issued: its Q registers are free for the next unit's rows.
         if (last && has_next) load_q(nxt[S_B] + bg, nxt[S_ROW0], nxt[S_L]);
-        // Touch the four 64-byte lines of the next step's lane mask now, so that the real loads further down
-        // find them in the scalar cache.
-        const int moff_n = nxt[S_MOFF];
-        const int tstep = moff_n ? 16 : 0;  // no mask: touch the table's first word only
-        const int touch0 = tab[moff_n], touch1 = tab[moff_n + tstep], touch2 = tab[moff_n + 2 * tstep], touch3 = tab[moff_n + 3 * tstep];
 
         STAMP(2);
-        // ---- V tile beyond the fp16 range? (rare; workgroup-uniform).  Checked here so that the LDS read of the
-        // tag is covered by the QK^T MFMAs.
+        // ---- V tile beyond the fp16 range? (rare; workgroup-uniform)
         int ve = 0;
-        {
-            const unsigned tg = vtag[bufc];
-            if ((tg >> 8) == seq) ve = min((int)(tg & 0xffu) - 142, 15);
-        }
+        if ((tg >> 8) == seq) ve = min((int)(tg & 0xffu) - 142, 15);
         if (ve > 0) {
             restage_v_scaled(bufc, b_cur, key0_cur, L_cur, ve);
             __syncthreads();
         }
+        // Touch the four 64-byte lines of the next step's lane mask now, so that the real loads further down
+        // find them in the scalar cache.  (After the tag has been looked at: scalar loads and LDS reads share one
+        // counter, and a wait for the tag behind these loads would wait for them too.)
+        const int moff_n = nxt[S_MOFF];
+        const int tstep = moff_n ? 16 : 0;  // no mask: touch the table's first word only
+        const int touch0 = tab[moff_n], touch1 = tab[moff_n + tstep], touch2 = tab[moff_n + 2 * tstep], touch3 = tab[moff_n + 3 * tstep];
+        // the record of the step after the next one, fetched here for the same reason
+        const i32x8 nn = steps[min(it + 2, s_end - 1)];
         // ---- online softmax (per query = per lane, halves combined by one exchange).  The running maximum is only
         // raised when some row's maximum grew by more than 2^RESCALE_LOG2 (or became finite for the first time):
         // until then probabilities may exceed 1 by at most that factor, which fp16 holds at full relative
