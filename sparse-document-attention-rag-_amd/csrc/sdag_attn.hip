@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
             } else if (p.out_f32) {
                 const int row = row0 + r;
                 if (head_ok && row < L_cur && !((ubits >> r) & 1u) && l_run > 0.f) {
-                    const float inv = 1.0f / l_run;
+                    const float inv = __builtin_amdgcn_rcpf(l_run);
                     float* op = reinterpret_cast<float*>(p.o) + (int64_t)b_cur * p.o_sb + (int64_t)row * p.o_sl + (int64_t)hq * p.o_sh;
 #pragma unroll
                     for (int db = 0; db < 4; ++db)
@@ -631,25 +631,38 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
                 // bf16 output through LDS so that every store instruction writes whole 256-byte rows.  The tile
                 // buffer just consumed is free until the end of the next step; the barrier below keeps the other
                 // waves from staging into it while this wave still reads its rows back.
-                unsigned char* stg = smem + (wave < 2 ? bufc : 2 + bufc) * TILE_BYTES + (wave & 1) * (TILE_BYTES / 2);
-                const float inv = 1.0f / l_run;  // rows that allow nothing are not stored
+                // Staging image: row rr at rr * 256, its 16-byte chunk ch at ((ch ^ (rr & 15)) << 4); the region starts
+                // on a multiple of 8 KiB, so the exclusive-or can be applied to the whole offset.
+                const unsigned stg = (unsigned)((wave < 2 ? bufc : 2 + bufc) * TILE_BYTES + (wave & 1) * (TILE_BYTES / 2));
+                const float inv = __builtin_amdgcn_rcpf(l_run);  // rows that allow nothing are not stored
+                const unsigned wofs = stg + (unsigned)(r * 256 + ((r & 15) << 4) + 8 * h);
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        bf16x4 w = {(__bf16)(oacc[db][4 * g] * inv), (__bf16)(oacc[db][4 * g + 1] * inv),
-                                    (__bf16)(oacc[db][4 * g + 2] * inv), (__bf16)(oacc[db][4 * g + 3] * inv)};
-                        *reinterpret_cast<bf16x4*>(stg + r * 256 + (((4 * db + g) ^ (r & 15)) << 4) + 8 * h) = w;
+                        unsigned lo, hi;
+                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(oacc[db][4 * g] * inv), "v"(oacc[db][4 * g + 1] * inv));
+                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(oacc[db][4 * g + 2] * inv), "v"(oacc[db][4 * g + 3] * inv));
+                        *reinterpret_cast<uint2*>(smem + (wofs ^ (unsigned)((4 * db + g) << 4))) = make_uint2(lo, hi);
                     }
-                const int ch = lane & 15;
-                unsigned short* ob = reinterpret_cast<unsigned short*>(p.o) + (int64_t)b_cur * p.o_sb + (int64_t)hq * p.o_sh + ch * 8;
+                // Read back as whole rows: lane -> chunk (lane & 15) of row 4 j + (lane >> 4).  The stores go through a
+                // buffer descriptor that ends with the sequence's last row; a lane with nothing to store gets an
+                // offset beyond it (dropped by the hardware), so the eight stores need no branches.
+                const int ch = lane & 15, q4 = lane >> 4;
+                const unsigned rofs = stg + (unsigned)(q4 * 256 + ((ch ^ q4) << 4));
+                u32x4 wv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    wv[j] = *reinterpret_cast<const u32x4*>(smem + ((rofs ^ (unsigned)((j & 3) << 6)) + (unsigned)(j * 1024)));
+                unsigned short* ob = reinterpret_cast<unsigned short*>(p.o) + (int64_t)b_cur * p.o_sb + (int64_t)hq * p.o_sh;
+                const unsigned orow = (unsigned)p.o_sl * 2u;
+                const auto ors = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((unsigned)(L_cur - 1) * orow + (unsigned)(D * 2)), 0x00020000);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int rr = 4 * j + (lane >> 4);
-                    const u32x4 w = *reinterpret_cast<const u32x4*>(stg + rr * 256 + ((ch ^ (rr & 15)) << 4));
-                    const int row = row0 + rr;
-                    if (head_ok && row < L_cur && !((ubits >> rr) & 1u))
-                        *reinterpret_cast<u32x4*>(ob + (int64_t)row * p.o_sl) = w;
+                    const int rr = 4 * j + q4;
+                    const bool keep = head_ok && !((ubits >> rr) & 1u);
+                    const unsigned off = keep ? (unsigned)(row0 + rr) * orow + (unsigned)ch * 16u : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(wv[j], ors, off, 0, 0);
                 }
                 __syncthreads();
             }
@@ -848,6 +861,7 @@ int check_common(const Tensors& t, int B, int Hq, int Hkv, int L, int Dh, float 
         if (st < 0 || (st & 7) || st > 0x7fffffff) return fail(SDAG_ERR_ARG, "strides must be non-negative multiples of 8 elements below 2^31");
     if ((int64_t)L * t.k_sl * 2 >= (1ll << 32) || (int64_t)L * t.v_sl * 2 >= (1ll << 32))
         return fail(SDAG_ERR_ARG, "one (batch, head) slice of K or V must span less than 4 GiB");
+    if ((int64_t)L * t.o_sl * 2 >= (1ll << 31)) return fail(SDAG_ERR_ARG, "one (batch, head) slice of O must span less than 2 GiB");
     if (((uintptr_t)t.q | (uintptr_t)t.k | (uintptr_t)t.v | (uintptr_t)t.o) & 15) return fail(SDAG_ERR_ARG, "tensor pointers must be 16-byte aligned");
     return SDAG_OK;
 }
