@@ -211,6 +211,8 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     const bool head_ok = hin < p.G;
     const int hq = kvh * p.G + (head_ok ? hin : p.G - 1);
     unsigned* vtag = reinterpret_cast<unsigned*>(smem + 4 * TILE_BYTES);
+    // LDS byte address of smem (what m0 takes for LDS-DMA)
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     if (tid < 2) vtag[tid] = 0;
 
     const int r = lane & 31;  // query row inside the block (S^T / O^T column)
@@ -265,9 +267,12 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     {                                                                                                         \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
             vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff0 + i * vstep, 0, 0)); \
+        /* (asm: behind the builtin the compiler orders every later LDS read after these writes with a full    \
+           vmcnt(0), in the middle of the step; the wait that covers them is the one at the step's end) */     \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)(smem + (BUF_) * TILE_BYTES + (4 * i + wave) * 1024), \
-                                                 16, koff0 + i * kstep, 0, 0, 0);                             \
+            asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"                         \
+                         :: "s"((unsigned)((BUF_) * TILE_BYTES + (4 * i + wave) * 1024) + smem_base),          \
+                            "v"(koff0 + i * kstep), "s"(krs) : "memory", "m0");                               \
     }
     // V goes to LDS as fp16: P V then runs on the f16 MFMA with 11-bit probabilities instead of 8-bit ones.
     // bf16 -> fp16 is exact for 2^-14 <= |v| < 2^16; round-toward-zero conversion saturates larger values
