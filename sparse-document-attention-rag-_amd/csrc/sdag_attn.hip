@@ -478,8 +478,9 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
         // find them in the scalar cache.  (After the tag has been looked at: scalar loads and LDS reads share one
         // counter, and a wait for the tag behind these loads would wait for them too.)
         const int moff_n = nxt[S_MOFF];
-        const int tstep = moff_n ? 16 : 0;  // no mask: touch the table's first word only
-        const int touch0 = tab[moff_n], touch1 = tab[moff_n + tstep], touch2 = tab[moff_n + 2 * tstep], touch3 = tab[moff_n + 3 * tstep];
+        // (no mask: the first four lines of the table, which every table has and which stay cached)
+        const AS4 int32_t* tp = tab + moff_n;
+        const int touch0 = tp[0], touch1 = tp[16], touch2 = tp[32], touch3 = tp[48];
         // the record of the step after the next one, fetched here for the same reason
         const i32x8 nn = steps[min(it + 2, s_end - 1)];
         // ---- online softmax (per query = per lane, halves combined by one exchange).  The running maximum is only
