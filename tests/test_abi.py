@@ -35,6 +35,19 @@ def test_error_reporting_without_gpu():
     assert rc == _lib.SDAG_ERR_CAPACITY and need.value > 32
     assert lib.sdag_dense_workspace_bytes(32, 1000, 64, 100) < 0   # k above the maximum
     assert lib.sdag_attn_workspace_bytes(None, 1, 4, 1) < 0
+    # sdag_attn_fwd checks its arguments before it touches the device (the pointers are never dereferenced here)
+    fake = 0x10000
+
+    def attn(L=64, D=128, o_sl=4 * 128, ptr=fake, scale=0.1):
+        q_sl = 4 * 128
+        return lib.sdag_attn_fwd(ptr, fake, fake, fake, L * q_sl, 128, q_sl, L * 128, 128, 128, L * 128, 128, 128,
+                                 0, o_sl, 128, 1, 4, 1, L, D, scale, None, None, None, 0, 0, None)  # B = 1: o_sb unused
+
+    assert attn(D=64) == _lib.SDAG_ERR_ARG and b"head_dim" in lib.sdag_last_error()
+    assert attn(scale=0.0) == _lib.SDAG_ERR_ARG and b"scale" in lib.sdag_last_error()
+    assert attn(ptr=fake + 8) == _lib.SDAG_ERR_ARG and b"aligned" in lib.sdag_last_error()
+    assert attn(L=1 << 20, o_sl=2048) == _lib.SDAG_ERR_ARG and b"slice of O" in lib.sdag_last_error()
+    assert attn() == _lib.SDAG_ERR_DESC   # everything else in order: the missing descriptor is what is reported
 
 
 def test_product_package_never_imports_the_oracle():
