@@ -387,296 +387,22 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
 #endif
-    int bufc = 0;
     unsigned seq = 1u;
 #ifdef SDAG_WGTIMES
     const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (int it = s_begin; it < s_end; ++it, ++seq) {
-        const bool has_next = it + 1 < s_end;
-        const int b_cur = cur[S_B] + bg, key0_cur = cur[S_KEY0], L_cur = cur[S_L];
-        const bool first = (cur[S_FLAGS] & 1) != 0, last = (cur[S_FLAGS] & 2) != 0;
-        if (first) {
-            m_run = -INFINITY;
-            l_run = 0.f;
-#pragma unroll
-            for (int db = 0; db < 4; ++db)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
-        }
-
-        const unsigned char* kb_lds = smem + bufc * TILE_BYTES;
-        const unsigned char* vb_lds = smem + (2 + bufc) * TILE_BYTES;
-
-        STAMP(0);
-        SDAG_TILE_RSRC(nxt[S_B] + bg, nxt[S_KEY0], nxt[S_L]);
-        // The V-range tag of this tile: read first, so that it has arrived long before it is looked at.
-        const unsigned tg = vtag[bufc];
-        // ---- S^T = K Q^T : two 32-key blocks on top of the accumulators prepared from the mask.
-        {
-            bf16x8 ka[8], kb2[8];
-#define SDAG_K_READ(KS_)                                                                                      \
-    {                                                                                                         \
-        const int ch_ = ((2 * (KS_) + h) ^ kf) << 4;                                                          \
-        ka[KS_] = *reinterpret_cast<const bf16x8*>(kb_lds + k_row_off + ch_);                                 \
-        kb2[KS_] = *reinterpret_cast<const bf16x8*>(kb_lds + 32 * 256 + k_row_off + ch_);                     \
-    }
-            SDAG_K_READ(0);
-            SDAG_K_READ(1);
-            SDAG_K_READ(2);
-            // A tile without a mask starts its products from a constant zero (no accumulator initialisation).
-            if (cur[S_MOFF]) {
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0], qf[0], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[0], qf[0], s1, 0, 0, 0);
-            } else {
-                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0], qf[0], zero, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[0], qf[0], zero, 0, 0, 0);
-            }
-            SDAG_K_READ(3);
-            SDAG_K_READ(4);
-            SDAG_K_READ(5);
-            SDAG_K_READ(6);
-            SDAG_K_READ(7);
-#undef SDAG_K_READ
-#pragma unroll
-            for (int ks = 1; ks < 8; ++ks) {
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[ks], qf[ks], s1, 0, 0, 0);
-            }
-            // The next step's K/V rows are requested from inside the MFMA stream (a stream's last step requests
-            // its own tile again): a vector-memory instruction holds the wave's issue for about as long as three
-            // MFMAs run, which is free here and a stall anywhere else.
-            SDAG_STAGE_LOADS(bufc ^ 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 ds_read (6 more ran ahead of the first products)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 ds_read
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 buffer load
-            }
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-        STAMP(1);
-        // The unit's last product is issued: its Q registers are free for the next unit's rows.
-        if (last && has_next) load_q(nxt[S_B] + bg, nxt[S_ROW0], nxt[S_L]);
-
-        STAMP(2);
-        // ---- V tile beyond the fp16 range? (rare; workgroup-uniform)
-        int ve = 0;
-        if ((tg >> 8) == seq) ve = min((int)(tg & 0xffu) - 142, 15);
-        if (ve > 0) {
-            restage_v_scaled(bufc, b_cur, key0_cur, L_cur, ve);
-            __syncthreads();
-        }
-        // Touch the four 64-byte lines of the next step's lane mask now, so that the real loads further down
-        // find them in the scalar cache.  (After the tag has been looked at: scalar loads and LDS reads share one
-        // counter, and a wait for the tag behind these loads would wait for them too.)
-        const int moff_n = nxt[S_MOFF];
-        // (no mask: the first four lines of the table, which every table has and which stay cached)
-        const AS4 int32_t* tp = tab + moff_n;
-        const int touch0 = tp[0], touch1 = tp[16], touch2 = tp[32], touch3 = tp[48];
-        // the record of the step after the next one, fetched here for the same reason
-        const i32x8 nn = steps[min(it + 2, s_end - 1)];
-        // ---- online softmax (per query = per lane, halves combined by one exchange).  The running maximum is only
-        // raised when some row's maximum grew by more than 2^RESCALE_LOG2 (or became finite for the first time):
-        // until then probabilities may exceed 1 by at most that factor, which fp16 holds at full relative
-        // precision, and the 64-register rescale of O is skipped.  A scaled V tile (ve > 0) always takes the exact
-        // maximum so that p * 2^ve stays inside fp16.
-        float mx = fmaxf(s0[0], s1[0]);
-#pragma unroll
-        for (int i = 1; i < 16; ++i) mx = max3(mx, s0[i], s1[i]);
-        mx = half_max(mx);
-        const float m_new = fmaxf(m_run, mx);
-        const bool grow = (m_new - m_run) * c > RESCALE_LOG2;  // -inf -> finite: true; -inf -> -inf: NaN, false
-        const bool rescale = __builtin_amdgcn_ballot_w64(grow) != 0 || ve > 0;
-        const float m_use = rescale ? m_new : m_run;
-        const float m_safe = (m_use == -INFINITY) ? 0.f : m_use;
-        const float alpha = rescale ? fast_exp2((m_run - m_safe) * c) : 1.0f;
-        const float nb = (float)ve - m_safe * c;  // probabilities carry 2^ve when V was scaled by 2^-ve
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            s0[i] = fast_exp2(__builtin_fmaf(s0[i], c, nb));
-            s1[i] = fast_exp2(__builtin_fmaf(s1[i], c, nb));
-        }
-
-        // ---- P^T fragments in fp16: registers 8 s .. 8 s + 7 of block kb are k-step (kb, s) of the B operand.
-        // Round-toward-zero packing (one instruction per pair); the row sum is taken over the ROUNDED
-        // probabilities, the values the MFMA multiplies with, so that the output stays an exact convex
-        // combination of V rows and the rounding (bias included) cancels against the normaliser.
-        f16x8 pf[2][2];
-        float rs0 = 0.f, rs1 = 0.f;
-        const f16x2 ones = {(_Float16)1.0f, (_Float16)1.0f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f16x2 t;
-            t = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(s0[2 * j], s0[2 * j + 1]));
-            pf[0][0][2 * j] = t[0]; pf[0][0][2 * j + 1] = t[1];
-            rs0 = __builtin_amdgcn_fdot2(t, ones, rs0, false);
-            t = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(s0[8 + 2 * j], s0[8 + 2 * j + 1]));
-            pf[0][1][2 * j] = t[0]; pf[0][1][2 * j + 1] = t[1];
-            rs1 = __builtin_amdgcn_fdot2(t, ones, rs1, false);
-            t = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(s1[2 * j], s1[2 * j + 1]));
-            pf[1][0][2 * j] = t[0]; pf[1][0][2 * j + 1] = t[1];
-            rs0 = __builtin_amdgcn_fdot2(t, ones, rs0, false);
-            t = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(s1[8 + 2 * j], s1[8 + 2 * j + 1]));
-            pf[1][1][2 * j] = t[0]; pf[1][1][2 * j + 1] = t[1];
-            rs1 = __builtin_amdgcn_fdot2(t, ones, rs1, false);
-        }
-        float rs = rs0 + rs1;
-        rs = half_sum(rs);
-        if (ve > 0) rs *= __uint_as_float((unsigned)(127 - ve) << 23);
-        if (rescale) {
-            l_run = l_run * alpha + rs;
-            m_run = m_new;
-            if (!first) {  // O is still zero on a unit's first tile
-#pragma unroll
-                for (int db = 0; db < 4; ++db)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
-            }
-        } else {
-            l_run += rs;
-        }
-
-        STAMP(3);
-        // ---- O^T += V^T P^T as 16 pinned groups, one MFMA each: the transposed reads of V run two groups ahead of
-        // the MFMA that consumes them, and every group carries one sixteenth of the staging work (the rows
-        // requested above are converted and written to the other tile buffer; nobody reads that buffer before the
-        // barrier below).  The scheduling barriers keep the compiler from regrouping the reads behind the MFMAs.
-        {
-            s16x4 va[4][2];
-#define SDAG_PV_READ(I_)                                                                                      \
-    {                                                                                                         \
-        const int db_ = (I_) >> 2, rbase_ = (32 * (((I_) >> 1) & 1) + 16 * ((I_) & 1)) * 256;                 \
-        va[(I_) & 3][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                                            \
-            (__attribute__((address_space(3))) s16x4*)(vb_lds + rbase_ + v_off[db_][0]));                     \
-        va[(I_) & 3][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                                            \
-            (__attribute__((address_space(3))) s16x4*)(vb_lds + rbase_ + 8 * 256 + v_off[db_][1]));           \
-    }
-            SDAG_PV_READ(0);
-            SDAG_PV_READ(1);
-            unsigned char* vd = smem + (2 + (bufc ^ 1)) * TILE_BYTES + st_off;
-            u32x4 hv;
-            vmax = 0.f;
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (i + 2 < 16) SDAG_PV_READ(i + 2);
-                {
-                    const int li_ = i >> 2, lj_ = i & 3;
-                    const unsigned w = vreg[li_][lj_];
-                    const float f0 = __uint_as_float(w << 16), f1 = __uint_as_float(w & 0xffff0000u);
-                    vmax = max3_abs(vmax, f0, f1);
-                    hv[lj_] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(f0, f1));
-                    if (lj_ == 3) *reinterpret_cast<u32x4*>(vd + li_ * 16 * 256) = hv;
-                }
-                {
-                    union { s16x4 hlf[2]; f16x8 full; } u;
-                    u.hlf[0] = va[i & 3][0];
-                    u.hlf[1] = va[i & 3][1];
-                    oacc[i >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(u.full, pf[(i >> 1) & 1][i & 1], oacc[i >> 2], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#undef SDAG_PV_READ
-        }
-
-        STAMP(4);
-        asm volatile("" ::"s"(touch0), "s"(touch1), "s"(touch2), "s"(touch3));
-        SDAG_INIT_SCORES(moff_n);
-        stage_tag(bufc ^ 1, seq + 1u);
-        STAMP(5);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's K pieces of the next tile have landed
-        __syncthreads();
-        STAMP(6);
-
-        // ---- end of a unit.  O^T register i of block db is column d = 32 db + (i & 3) + 8 (i >> 2) + 4 h of the
-        // lane's row.
-        if (last) {
-            const int row0 = cur[S_ROW0];
-            const int slot = cur[S_SLOT];
-            const unsigned ubits = (unsigned)cur[S_UBITS];
-            if (slot >= 0) {
-                if (head_ok) {
-                    const int64_t gslot = (int64_t)slot + (int64_t)bg * p.slots_per_b;
-                    const int64_t prow = (gslot * p.Hq + hq) * RB + r;
-                    float* po = p.part_o + prow * D;
-#pragma unroll
-                    for (int db = 0; db < 4; ++db)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            f32x4 w = {oacc[db][4 * g], oacc[db][4 * g + 1], oacc[db][4 * g + 2], oacc[db][4 * g + 3]};
-                            *reinterpret_cast<f32x4*>(po + 32 * db + 8 * g + 4 * h) = w;
-                        }
-                    if (h == 0) {
-                        p.part_ml[prow * 2] = m_run;
-                        p.part_ml[prow * 2 + 1] = l_run;
-                    }
-                }
-            } else if (p.out_f32) {
-                const int row = row0 + r;
-                if (head_ok && row < L_cur && !((ubits >> r) & 1u) && l_run > 0.f) {
-                    const float inv = __builtin_amdgcn_rcpf(l_run);
-                    float* op = reinterpret_cast<float*>(p.o) + (int64_t)b_cur * p.o_sb + (int64_t)row * p.o_sl + (int64_t)hq * p.o_sh;
-#pragma unroll
-                    for (int db = 0; db < 4; ++db)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            f32x4 w = {oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv, oacc[db][4 * g + 2] * inv,
-                                       oacc[db][4 * g + 3] * inv};
-                            *reinterpret_cast<f32x4*>(op + 32 * db + 8 * g + 4 * h) = w;
-                        }
-                }
-            } else {
-                // bf16 output through LDS so that every store instruction writes whole 256-byte rows.  The tile
-                // buffer just consumed is free until the end of the next step; the barrier below keeps the other
-                // waves from staging into it while this wave still reads its rows back.
-                // Staging image: row rr at rr * 256, its 16-byte chunk ch at ((ch ^ (rr & 15)) << 4); the region starts
-                // on a multiple of 8 KiB, so the exclusive-or can be applied to the whole offset.
-                const unsigned stg = (unsigned)((wave < 2 ? bufc : 2 + bufc) * TILE_BYTES + (wave & 1) * (TILE_BYTES / 2));
-                const float inv = __builtin_amdgcn_rcpf(l_run);  // rows that allow nothing are not stored
-                const unsigned wofs = stg + (unsigned)(r * 256 + ((r & 15) << 4) + 8 * h);
-#pragma unroll
-                for (int db = 0; db < 4; ++db)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        unsigned lo, hi;
-                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(oacc[db][4 * g] * inv), "v"(oacc[db][4 * g + 1] * inv));
-                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(oacc[db][4 * g + 2] * inv), "v"(oacc[db][4 * g + 3] * inv));
-                        *reinterpret_cast<uint2*>(smem + (wofs ^ (unsigned)((4 * db + g) << 4))) = make_uint2(lo, hi);
-                    }
-                // Read back as whole rows: lane -> chunk (lane & 15) of row 4 j + (lane >> 4).  The stores go through a
-                // buffer descriptor that ends with the sequence's last row; a lane with nothing to store gets an
-                // offset beyond it (dropped by the hardware), so the eight stores need no branches.
-                const int ch = lane & 15, q4 = lane >> 4;
-                const unsigned rofs = stg + (unsigned)(q4 * 256 + ((ch ^ q4) << 4));
-                u32x4 wv[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    wv[j] = *reinterpret_cast<const u32x4*>(smem + ((rofs ^ (unsigned)((j & 3) << 6)) + (unsigned)(j * 1024)));
-                unsigned short* ob = reinterpret_cast<unsigned short*>(p.o) + (int64_t)b_cur * p.o_sb + (int64_t)hq * p.o_sh;
-                const unsigned orow = (unsigned)p.o_sl * 2u;
-                const auto ors = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((unsigned)(L_cur - 1) * orow + (unsigned)(D * 2)), 0x00020000);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int rr = 4 * j + q4;
-                    const bool keep = head_ok && !((ubits >> rr) & 1u);
-                    const unsigned off = keep ? (unsigned)(row0 + rr) * orow + (unsigned)ch * 16u : 0x80000000u;
-                    __builtin_amdgcn_raw_buffer_store_b128(wv[j], ors, off, 0, 0);
-                }
-                __syncthreads();
-            }
-        }
-        STAMP(7);
-        bufc ^= 1;
-        cur = nxt;
-        nxt = nn;
+    // The loop body is written once (sdag_attn_step.inc) and expanded for either tile buffer.
+    for (int it = s_begin;;) {
+#define SDAG_BUFC 0
+#include "sdag_attn_step.inc"
+#undef SDAG_BUFC
+        ++seq;
+        if (++it >= s_end) break;
+#define SDAG_BUFC 1
+#include "sdag_attn_step.inc"
+#undef SDAG_BUFC
+        ++seq;
+        if (++it >= s_end) break;
     }
 
 #ifdef SDAG_WGTIMES
