@@ -1,7 +1,7 @@
 #!/bin/bash
 # Counter passes over one microbench mode ($1): each pass its own run, at most 8 SQ counters.
 mode=${1:-one}
-out=gpurun_out/pmc_$mode
+out=gpurun_out/pmc_${mode%% *}
 rm -rf $out; mkdir -p $out
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
