@@ -263,16 +263,20 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     if ((B_) != b_kv) set_kv_base(B_);                                                                        \
     const auto krs = tile_rsrc(kbase, (unsigned)p.k_sl * 2u, (KEY0_), (L_));                                  \
     const auto vrs = tile_rsrc(vbase, (unsigned)p.v_sl * 2u, (KEY0_), (L_));
+    // one quarter of a tile's V rows (16 rows) into registers
+#define SDAG_V_LOAD(I_) \
+    vreg[I_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff0 + (I_) * vstep, 0, 0))
+    // one of this wave's four 1 KiB pieces of a tile's K rows into LDS.  (asm: behind the builtin the compiler orders
+    // every later LDS read after these writes with a full vmcnt(0), in the middle of the step; the wait that covers
+    // them is the one at the step's end)
+#define SDAG_K_DMA(BUF_, I_)                                                                                  \
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"                                 \
+                 :: "s"((unsigned)((BUF_) * TILE_BYTES + (4 * (I_) + wave) * 1024) + smem_base),               \
+                    "v"(koff0 + (I_) * kstep), "s"(krs) : "memory", "m0")
 #define SDAG_STAGE_LOADS(BUF_)                                                                                \
     {                                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
-            vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff0 + i * vstep, 0, 0)); \
-        /* (asm: behind the builtin the compiler orders every later LDS read after these writes with a full    \
-           vmcnt(0), in the middle of the step; the wait that covers them is the one at the step's end) */     \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
-            asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"                         \
-                         :: "s"((unsigned)((BUF_) * TILE_BYTES + (4 * i + wave) * 1024) + smem_base),          \
-                            "v"(koff0 + i * kstep), "s"(krs) : "memory", "m0");                               \
+        SDAG_V_LOAD(0); SDAG_V_LOAD(1); SDAG_V_LOAD(2); SDAG_V_LOAD(3);                                       \
+        SDAG_K_DMA(BUF_, 0); SDAG_K_DMA(BUF_, 1); SDAG_K_DMA(BUF_, 2); SDAG_K_DMA(BUF_, 3);                   \
     }
     // V goes to LDS as fp16: P V then runs on the f16 MFMA with 11-bit probabilities instead of 8-bit ones.
     // bf16 -> fp16 is exact for 2^-14 <= |v| < 2^16; round-toward-zero conversion saturates larger values
