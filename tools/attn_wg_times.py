@@ -33,17 +33,19 @@ o = torch.empty((B, L, 32, 128), device=dev, dtype=torch.bfloat16)
 call = sdag_amd.BoundBatchAttention(q, k, v, bd, o)
 for _ in range(3): call()
 torch.cuda.synchronize()
-buf = (ctypes.c_uint * (8192 * 4))()
+buf = (ctypes.c_uint * (8192 * 6))()
 f = ctypes.CDLL(os.environ["SDAG_HIP_LIB"]).sdag_debug_wg_ticks
 f.argtypes = [ctypes.c_void_p]; f.restype = ctypes.c_int
 assert f(buf) == 0
 nwg = 8 * ns
-a = np.frombuffer(buf, dtype=np.uint32).reshape(8192, 4)[:nwg].astype(np.int64)
+a = np.frombuffer(buf, dtype=np.uint32).reshape(8192, 6)[:nwg].astype(np.int64)
 t, nst, t0 = a[:, 0] / 100.0, a[:, 1], a[:, 2]
 start = ((t0 - t0.min()) & 0xffffffff) / 100.0
 end = start + t
 strm = (np.arange(nwg) // 8) % ns
 assert (nst == feat[strm, 0]).all()
+cyc = a[:, 4] + (a[:, 5] << 32)
+print(f"in-kernel shader clock (cycles / 100 MHz ticks): median {np.median(cyc / a[:, 0]) * 0.1:.3f} GHz, min {(cyc / a[:, 0]).min() * 0.1:.3f}, max {(cyc / a[:, 0]).max() * 0.1:.3f}; cycles per step median {np.median(cyc / nst):.0f}")
 print(f"{nwg} workgroups, {ns} streams: duration us min {t.min():.0f} mean {t.mean():.0f} max {t.max():.0f}; start spread {start.max():.1f}; end min {end.min():.0f} max {end.max():.0f}")
 X = np.column_stack([feat[strm, 0], feat[strm, 1], feat[strm, 2], np.ones(nwg)])
 coef, res, *_ = np.linalg.lstsq(X, t, rcond=None)
