@@ -28,8 +28,9 @@
 
 namespace sdag {
 #ifdef SDAG_WGTIMES
-// Diagnostic build only: per-workgroup wall time (100 MHz ticks), steps walked and start tick of the last launch.
-__device__ unsigned g_wg_ticks[8192][4];
+// Diagnostic build only: per-workgroup wall time (100 MHz ticks), steps walked, start tick, place and shader cycles
+// of the last launch.
+__device__ unsigned g_wg_ticks[8192][6];
 #endif
 #ifdef SDAG_STAMPS
 __device__ unsigned long long g_stamps[16];
@@ -394,6 +395,7 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     unsigned seq = 1u;
 #ifdef SDAG_WGTIMES
     const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long wg_c0 = __builtin_amdgcn_s_memtime();
 #endif
     // The loop body is written once (sdag_attn_step.inc) and expanded for either tile buffer.
     for (int it = s_begin;;) {
@@ -412,6 +414,9 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
 #ifdef SDAG_WGTIMES
     if (tid == 0 && blockIdx.x < 8192) {
         g_wg_ticks[blockIdx.x][0] = (unsigned)(__builtin_amdgcn_s_memrealtime() - wg_t0);
+        const unsigned long long wg_dc = __builtin_amdgcn_s_memtime() - wg_c0;  // shader-clock cycles
+        g_wg_ticks[blockIdx.x][4] = (unsigned)wg_dc;
+        g_wg_ticks[blockIdx.x][5] = (unsigned)(wg_dc >> 32);
         g_wg_ticks[blockIdx.x][1] = (unsigned)(s_end - s_begin);
         g_wg_ticks[blockIdx.x][2] = (unsigned)(wg_t0 & 0xffffffffu);
         // HW_ID bits 8-15 (CU, shader array, shader engine) and XCC_ID bits 0-3
@@ -719,7 +724,7 @@ extern "C" int sdag_mask_materialize(const int32_t* desc_host, const int32_t* de
 #ifdef SDAG_WGTIMES
 extern "C" int sdag_debug_wg_ticks(unsigned* out) {
     SDAG_HIP_CHECK(hipDeviceSynchronize());
-    SDAG_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(sdag::g_wg_ticks), sizeof(unsigned) * 8192 * 4));
+    SDAG_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(sdag::g_wg_ticks), sizeof(unsigned) * 8192 * 6));
     return SDAG_OK;
 }
 #endif
