@@ -45,18 +45,24 @@ struct SchedUnit {
     int64_t lmask_base;    // word offset (from the start of the table the steps live in) of that sequence's lane masks
 };
 
+inline int64_t unit_cost(const SchedUnit& u) { return (u.item_end - u.item_begin) + 2; }
+
 // Deal the units, in the order given, to n_streams streams: each goes to the stream with the least work so far
-// (cost = key tiles + a fixed charge per unit for loading Q and storing O).  Writes the stream offsets (in steps)
-// and the step records.
-void build_schedule(const std::vector<SchedUnit>& units, int n_streams, int32_t* stream_off, int32_t* steps) {
+// (cost = key tiles + a fixed charge per unit for loading Q and storing O); with `half` given (one entry per unit,
+// 0 or 1), only among the first or the second half of the streams.  Writes the stream offsets (in steps) and the
+// step records.
+void build_schedule(const std::vector<SchedUnit>& units, int n_streams, int32_t* stream_off, int32_t* steps,
+                    const std::vector<uint8_t>* half = nullptr) {
     std::vector<int64_t> load((size_t)n_streams, 0);
     std::vector<std::vector<int32_t>> mine((size_t)n_streams);
     for (size_t u = 0; u < units.size(); ++u) {
-        int best = 0;
-        for (int s = 1; s < n_streams; ++s)
+        const int lo = half ? ((*half)[u] ? n_streams / 2 : 0) : 0;
+        const int hi = half ? ((*half)[u] ? n_streams : n_streams / 2) : n_streams;
+        int best = lo;
+        for (int s = lo + 1; s < hi; ++s)
             if (load[s] < load[best]) best = s;
         mine[best].push_back((int32_t)u);
-        load[best] += (units[u].item_end - units[u].item_begin) + 2;
+        load[best] += unit_cost(units[u]);
     }
     int64_t n = 0;
     for (int s = 0; s < n_streams; ++s) {
@@ -442,6 +448,39 @@ extern "C" int sdag_batch_build(const int32_t* const* descs, int B, int n_stream
             su.push_back({b, u[7], u[1], u[2], u[3] < 0 ? -1 : slot_base[b] + u[3], u[4], d[H_L], d + d[H_OFF_ITEMS],
                           (int64_t)desc_off[b] + d[H_OFF_LMASKS]});
     }
-    build_schedule(su, n_streams, out + off_streams, out + off_steps);
+    // A batch with plenty of units per stream: the units of every sequence are cut in two by the keys they end at
+    // (the first documents | the last documents and the rows that see everything), at equal cost, and each part goes
+    // to one half of the streams.  Streams of one half then share their K/V rows with nobody outside it.  Why: the
+    // two workgroups a compute unit holds do not advance at the same speed (the one dispatched first wins the issue
+    // arbitration), blocks are dispatched in index order, so the first half of the streams runs ahead of the second by
+    // several sequences; with every stream reading every document, the rows a lagging stream needs have long left the
+    // L2 of its XCD.  Nothing depends on that dispatch order: without it the schedule is as balanced as the plain one.
+    std::vector<uint8_t> half;
+    if (n_streams >= 2 && n_streams % 2 == 0 && n_units >= 8 * (int64_t)n_streams) {
+        half.assign(su.size(), 0);
+        int64_t load2[2] = {0, 0};
+        size_t first = 0;
+        for (int b = 0; b < B; ++b) {
+            const size_t n_b = (size_t)descs[b][H_NUNITS];
+            std::vector<size_t> idx(n_b);
+            for (size_t k = 0; k < n_b; ++k) idx[k] = first + k;
+            auto last_key = [&](size_t u) { return su[u].items[2 * (su[u].item_end - 1)]; };
+            std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return last_key(x) < last_key(y); });
+            int64_t total = 0;
+            for (size_t u : idx) total += unit_cost(su[u]);
+            // the part that ends at the low keys goes to the half with less work so far, up to an even overall split
+            const int low = load2[0] <= load2[1] ? 0 : 1;
+            const int64_t want = (total + load2[1 - low] - load2[low]) / 2;
+            int64_t acc = 0;
+            for (size_t u : idx) {
+                const int h = acc + unit_cost(su[u]) / 2 <= want ? low : 1 - low;
+                half[u] = (uint8_t)h;
+                load2[h] += unit_cost(su[u]);
+                acc += unit_cost(su[u]);
+            }
+            first += n_b;
+        }
+    }
+    build_schedule(su, n_streams, out + off_streams, out + off_steps, half.empty() ? nullptr : &half);
     return SDAG_OK;
 }
