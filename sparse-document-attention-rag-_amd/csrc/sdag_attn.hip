@@ -148,7 +148,8 @@ __device__ void vsum_block(const AttnParams& p, int vb, unsigned char* smem) {
     const unsigned short* base = p.v + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh + cq * 4;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     for (int r = r0 + rl; r < r1; r += 8) {
-        const uint2 w = *reinterpret_cast<const uint2*>(base + (int64_t)r * p.v_sl);
+        typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+        const u32x2 w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(base + (int64_t)r * p.v_sl));  // read once
         s0 += __uint_as_float(w.x << 16);
         s1 += __uint_as_float(w.x & 0xffff0000u);
         s2 += __uint_as_float(w.y << 16);
