@@ -481,6 +481,30 @@ extern "C" int sdag_batch_build(const int32_t* const* descs, int B, int n_stream
             first += n_b;
         }
     }
+    if (!half.empty()) {
+        // ... and inside a sequence the units are dealt in the order of the keys they end at: the row blocks of one
+        // document then run at the same time on different streams, and its K/V rows are fetched into the L2 once for
+        // all of them (dealt longest first, they are spread over the time the sequence takes)
+        std::vector<size_t> perm(su.size());
+        for (size_t i = 0; i < perm.size(); ++i) perm[i] = i;
+        std::stable_sort(perm.begin(), perm.end(), [&](size_t x, size_t y) {
+            if (su[x].b != su[y].b) return su[x].b < su[y].b;
+            // (long units - rows that see most of the prompt - first: dealt last, they would unbalance the streams)
+            const bool lx = unit_cost(su[x]) >= 16, ly = unit_cost(su[y]) >= 16;
+            if (lx != ly) return lx;
+            return su[x].items[2 * (su[x].item_end - 1)] < su[y].items[2 * (su[y].item_end - 1)];
+        });
+        std::vector<SchedUnit> su2;
+        std::vector<uint8_t> h2;
+        su2.reserve(su.size());
+        h2.reserve(su.size());
+        for (size_t i : perm) {
+            su2.push_back(su[i]);
+            h2.push_back(half[i]);
+        }
+        su.swap(su2);
+        half.swap(h2);
+    }
     build_schedule(su, n_streams, out + off_streams, out + off_steps, half.empty() ? nullptr : &half);
     return SDAG_OK;
 }
