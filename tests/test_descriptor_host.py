@@ -138,3 +138,32 @@ def test_batch_table_streams():
     gl = sorted(int(s[6]) for s in steps if (s[2] & 2) and s[6] >= 0)
     assert gl == list(range(int(w[6])))                                # every global partial slot exactly once
     assert list(slot_base) == [0, a.n_slots, a.n_slots + b.n_slots]
+
+
+def test_batch_table_stream_halves():
+    """A batch with many units per stream: every sequence's units are cut in two by the keys they end at, one part
+    per half of the streams; every unit still appears exactly once and the streams carry about equal work."""
+    import sdag_amd
+
+    spans, qa, L = synthetic_layout(60, [300] * 10, 1, 30)
+    d = sdag_amd.from_spans(L, 60, spans, qa, max_items_per_unit=64)
+    B, ns = 6, 8
+    bt = sdag_amd.BatchDescriptor([d] * B, n_streams=ns)
+    w = bt.host
+    assert int(w[2]) == B and int(w[14]) == ns and d.n_units * B >= 8 * ns
+    doff = w[w[7]: w[7] + B]
+    seen, counts = check_schedule(w, int(w[17]), int(w[16]), ns, lambda i: (d.host, int(doff[i])))
+    assert len(seen) == B * d.n_units and counts.sum() == w[15] == B * d.n_items
+    so = w[int(w[16]): int(w[16]) + ns + 1]
+    steps = w[w[17]: w[17] + 8 * w[15]].reshape(-1, 8)
+    cost = np.zeros(ns, dtype=np.int64)
+    ends = {}  # (sequence, half of the streams) -> first keys of the last tiles of its units
+    for s in range(ns):
+        r = steps[so[s]: so[s + 1]]
+        cost[s] = len(r) + 2 * int((r[:, 2] & 1).sum())
+        for st in r[(r[:, 2] & 2) != 0]:
+            ends.setdefault((int(st[3]), s >= ns // 2), []).append(int(st[0]))
+    for b in range(B):
+        lo, hi = ends[(b, False)], ends[(b, True)]
+        assert max(lo) <= min(hi) or max(hi) <= min(lo)          # the two halves split the sequence by key range
+    assert cost.max() <= 1.2 * cost.mean()
