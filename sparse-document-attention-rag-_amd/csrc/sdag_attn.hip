@@ -6,19 +6,22 @@
 // repeat_kv, Q K^T * scaling + mask, fp32 softmax, P V, output [B, L, Hq, D]).
 //
 // Work decomposition
-//   One workgroup (4 waves) = one descriptor unit: a 32-row query block x a run of 64-key tiles, for ONE
-//   key/value head.  The four waves take four query heads that share that key/value head (grouped-query
-//   attention), so one K/V tile staged in LDS feeds four heads, and all four waves see the same mask.
+//   The host deals the descriptor's units (a 32-row query block x a run of 64-key tiles) to work streams; one
+//   persistent workgroup (4 waves) walks one stream for ONE key/value head, a step being one tile of one unit.  The
+//   four waves take four query heads that share that key/value head (grouped-query attention), so one K/V tile
+//   staged in LDS feeds four heads, and all four waves see the same mask.
 //   blockIdx % (Hkv * head_groups) selects the key/value head, so with 8 KV heads every block that reads a
 //   given head's K/V runs on the same XCD and shares that XCD's L2.
-// Per tile, per wave
-//   S^T = K Q^T   (16 x v_mfma_f32_32x32x16_bf16; keys in the accumulator rows, the query on the lane, so the
-//                  softmax row statistics are lane-local plus one exchange between the two 32-lane halves)
-//   online softmax in fp32 registers, masked by the tile's 32 x 64 bit mask when it has one
-//   O^T += V^T P^T (16 MFMAs; the S^T accumulators, converted to bf16, are directly the B operand; V^T comes
-//                  from LDS through ds_read_b64_tr_b16)
-// K and V tiles are register-staged (global_load_dwordx4 -> ds_write_b128) into an XOR-swizzled image that is
-// conflict-free for both the row reads of K and the transposed reads of V, double buffered, one barrier a tile.
+// Per step, per wave (the loop body is sdag_attn_step.inc)
+//   S^T = K Q^T   (16 x v_mfma_f32_32x32x16_bf16 on top of accumulators initialised from the tile's lane mask;
+//                  keys in the accumulator rows, the query on the lane, so the softmax row statistics are
+//                  lane-local plus one exchange between the two 32-lane halves)
+//   online softmax in fp32 registers with a deferred running maximum
+//   O^T += V^T P^T (16 x v_mfma_f32_32x32x16_f16; the S^T accumulators, converted to fp16, are directly the B
+//                  operand; V^T comes from LDS through ds_read_b64_tr_b16)
+// The next tile's K rows go from global memory straight into an XOR-swizzled LDS image (LDS-DMA); its V rows pass
+// through registers, where they are converted to fp16, into an image of the same shape; both images are
+// conflict-free for the row reads of K and the transposed reads of V, double buffered, one barrier a step.
 // Row blocks with long tile runs are split into several units; their partial (O, m, l) go to a workspace and a
 // second kernel merges them.  Rows that allow nothing get mean(V) (uniform softmax over all L keys), from
 // per-chunk column sums that extra blocks of the main launch compute.
