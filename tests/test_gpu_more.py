@@ -333,6 +333,32 @@ def test_attention_batch_of_different_prompts():
     assert torch.equal(o2[:, :L], single)
 
 
+def test_attention_batch_with_stream_halves():
+    """A batch with many units per stream (the table cuts every sequence's units in two by key range, one part per
+    half of the streams, and deals them in key order): same bits as one launch per sequence, and the oracle's values."""
+    import sdag_amd
+    from oracle import sdag_ref
+
+    spans, qa, L = synthetic_layout(20, [90, 70, 100, 64], 1, 12)
+    nbr = [[1], [2], [3], [0]]
+    B, Hq, Hkv = 6, 8, 2
+    d = sdag_amd.from_spans(L, 20, spans, qa, nbr, max_items_per_unit=64)
+    batch = sdag_amd.BatchDescriptor([d] * B, n_streams=2)
+    assert d.n_units * B >= 8 * 2                                   # enough units per stream for the split
+    g = torch.Generator().manual_seed(33)
+    q = torch.randn(B, Hq, L, 128, generator=g).to(torch.bfloat16)
+    k = torch.randn(B, Hkv, L, 128, generator=g).to(torch.bfloat16)
+    v = torch.randn(B, Hkv, L, 128, generator=g).to(torch.bfloat16)
+    for dt in (torch.float32, torch.bfloat16):
+        ob = sdag_amd.sdag_attention_batch(q.to(DEV), k.to(DEV), v.to(DEV), batch, out_dtype=dt).cpu()
+        os_ = sdag_amd.sdag_attention(q.to(DEV), k.to(DEV), v.to(DEV), d, out_dtype=dt).cpu()
+        assert torch.equal(ob, os_), dt
+    mask = torch.from_numpy(sdag_ref.mask_from_spans(L, 20, spans, qa, nbr))
+    ref = sdag_ref.masked_attention(q, k, v, mask, 128 ** -0.5)
+    o32 = sdag_amd.sdag_attention_batch(q.to(DEV), k.to(DEV), v.to(DEV), batch, out_dtype=torch.float32).cpu()
+    assert _rel_err(o32, ref) <= 1e-3
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
 def test_attention_random_layouts_streams_and_bf16_rows(seed):
     """Random ragged layouts (empty documents, out-of-range neighbour ids, overlapping spans), random stream
