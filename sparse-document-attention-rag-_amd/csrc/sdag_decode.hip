@@ -82,8 +82,18 @@ __global__ __launch_bounds__(64) void sdag_decode_main(const DecodeParams p) {
     for (int g = g_begin; g < g_end; ++g) {
         const int key = g * 64 + lane;
         const bool live = key < p.S;
-        // ---- scores of this lane's key against the query rows
+        // ---- all loads of the group first: this lane's K row (16 x 16 bytes) and, coalesced, one 4-byte column pair
+        // of each of the 64 V rows, so that the V rows travel while the scores are computed (rows past the end of
+        // the sequence are clamped to the last key; their probability is 0)
         const u32x4* krow = reinterpret_cast<const u32x4*>(kh + (int64_t)min(key, p.S - 1) * p.k_sl);
+        u32x4 kreg[16];
+#pragma unroll
+        for (int ch = 0; ch < 16; ++ch) kreg[ch] = krow[ch];
+        const unsigned* vbase = reinterpret_cast<const unsigned*>(vh) + lane;
+        unsigned vw[64];
+#pragma unroll
+        for (int t = 0; t < 64; ++t) vw[t] = vbase[(int64_t)min(g * 64 + t, p.S - 1) * (p.v_sl / 2)];
+        // ---- scores of this lane's key against the query rows
         float s[GW] = {0.f, 0.f, 0.f, 0.f};
         // the query words are re-read through the scalar cache for every group of keys: 256 of them do not fit
         // the scalar registers, and keeping the pointers opaque stops the compiler from hoisting the loads
@@ -92,7 +102,7 @@ __global__ __launch_bounds__(64) void sdag_decode_main(const DecodeParams p) {
         for (int j = 0; j < GW; ++j) asm volatile("" : "+s"(qrow[j]));
 #pragma unroll
         for (int ch = 0; ch < 16; ++ch) {
-            const u32x4 kk = krow[ch];
+            const u32x4 kk = kreg[ch];
             const unsigned kw[4] = {kk.x, kk.y, kk.z, kk.w};
 #pragma unroll
             for (int j = 0; j < GW; ++j) {
@@ -117,22 +127,16 @@ __global__ __launch_bounds__(64) void sdag_decode_main(const DecodeParams p) {
             o1[j] *= alpha;
             m[j] = m_new;
         }
-        // ---- O += P V: one coalesced 256-byte V row per key, its probability read out of the key's lane
-        // (lanes past the end of the sequence hold probability 0; their rows are clamped to the last key)
-        const int n_live = min(64, p.S - g * 64);
-        const unsigned* vbase = reinterpret_cast<const unsigned*>(vh) + lane;
-        for (int t0 = 0; t0 < n_live; t0 += 8) {
+        // ---- O += P V: each key's probability read out of the key's lane
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int t = t0 + u;
-                const unsigned w = vbase[(int64_t)min(g * 64 + t, p.S - 1) * (p.v_sl / 2)];
-                const float v0 = __uint_as_float(w << 16), v1 = __uint_as_float(w & 0xffff0000u);
+        for (int t = 0; t < 64; ++t) {
+            const unsigned w = vw[t];
+            const float v0 = __uint_as_float(w << 16), v1 = __uint_as_float(w & 0xffff0000u);
 #pragma unroll
-                for (int j = 0; j < GW; ++j) {
-                    const float pj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pr[j]), t));
-                    o0[j] = __builtin_fmaf(pj, v0, o0[j]);
-                    o1[j] = __builtin_fmaf(pj, v1, o1[j]);
-                }
+            for (int j = 0; j < GW; ++j) {
+                const float pj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pr[j]), t));
+                o0[j] = __builtin_fmaf(pj, v0, o0[j]);
+                o1[j] = __builtin_fmaf(pj, v1, o1[j]);
             }
         }
     }
@@ -149,25 +153,49 @@ __global__ __launch_bounds__(64) void sdag_decode_main(const DecodeParams p) {
     }
 }
 
-// One block of 128 threads per (sequence, query head): log-sum-exp merge of the parts, one column per thread.
-__global__ __launch_bounds__(128) void sdag_decode_merge(const DecodeParams p) {
+// One block of 256 threads per (sequence, query head): log-sum-exp merge of the parts.  Thread -> column pair
+// (tid & 63), parts tid >> 6, + 4, + 8, ...: every load is independent of the others, and the four partial sums per
+// column meet in LDS.
+__global__ __launch_bounds__(256) void sdag_decode_merge(const DecodeParams p) {
+    __shared__ float red_m[4];
+    __shared__ float red_den[4];
+    __shared__ float2 red_o[4][64];
     const int hq = blockIdx.x % p.Hq, b = blockIdx.x / p.Hq;
-    const int col = threadIdx.x;
+    const int tid = threadIdx.x, cp = tid & 63, pg = tid >> 6;
     const float* src = p.part + ((int64_t)b * p.Hq + hq) * p.n_parts * PART_STRIDE;
-    float mmax = -INFINITY;
-    for (int t = 0; t < p.n_parts; ++t) mmax = fmaxf(mmax, src[t * PART_STRIDE + D]);
-    float acc = 0.f, den = 0.f;
-    for (int t = 0; t < p.n_parts; ++t) {
-        const float w = __builtin_amdgcn_exp2f(src[t * PART_STRIDE + D] - mmax);  // empty part: m = -inf -> 0
-        den += w * src[t * PART_STRIDE + D + 1];
-        acc += w * src[t * PART_STRIDE + col];
+    // the largest running maximum of all parts (at most 128 parts: one per thread of the first two waves)
+    float mx = tid < p.n_parts ? src[tid * PART_STRIDE + D] : -INFINITY;
+    mx = wave_max(mx);
+    if (cp == 0) red_m[pg] = mx;
+    __syncthreads();
+    const float mmax = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+    float2 acc = make_float2(0.f, 0.f);
+    float den = 0.f;
+#pragma unroll 4
+    for (int t = pg; t < p.n_parts; t += 4) {
+        const float* s = src + t * PART_STRIDE;
+        const float w = __builtin_amdgcn_exp2f(s[D] - mmax);  // empty part: m = -inf -> 0
+        const float2 x = reinterpret_cast<const float2*>(s)[cp];
+        den += w * s[D + 1];
+        acc.x += w * x.x;
+        acc.y += w * x.y;
     }
-    const float r = acc / den;
-    const int64_t oi = (int64_t)b * p.o_sb + (int64_t)hq * p.o_sh + col;
-    if (p.out_f32)
-        reinterpret_cast<float*>(p.o)[oi] = r;
-    else
-        reinterpret_cast<__bf16*>(p.o)[oi] = (__bf16)r;
+    red_o[pg][cp] = acc;
+    if (cp == 0) red_den[pg] = den;
+    __syncthreads();
+    if (pg != 0) return;
+    const float dsum = (red_den[0] + red_den[1]) + (red_den[2] + red_den[3]);
+    const float inv = 1.0f / dsum;
+    const float r0 = ((red_o[0][cp].x + red_o[1][cp].x) + (red_o[2][cp].x + red_o[3][cp].x)) * inv;
+    const float r1 = ((red_o[0][cp].y + red_o[1][cp].y) + (red_o[2][cp].y + red_o[3][cp].y)) * inv;
+    const int64_t oi = (int64_t)b * p.o_sb + (int64_t)hq * p.o_sh + 2 * cp;
+    if (p.out_f32) {
+        *reinterpret_cast<float2*>(reinterpret_cast<float*>(p.o) + oi) = make_float2(r0, r1);
+    } else {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+        bf16x2_t w = {(__bf16)r0, (__bf16)r1};
+        *reinterpret_cast<bf16x2_t*>(reinterpret_cast<__bf16*>(p.o) + oi) = w;
+    }
 }
 
 void plan(int S, int* n_parts, int* groups_per_part) {
@@ -220,7 +248,7 @@ extern "C" int sdag_decode_attn(const void* q, const void* k, const void* v, voi
     if (blocks > 0x7fffffff) return fail(SDAG_ERR_ARG, "grid too large");
     hipLaunchKernelGGL(sdag_decode_main, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, p);
     SDAG_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(sdag_decode_merge, dim3((unsigned)(B * Hq)), dim3(128), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(sdag_decode_merge, dim3((unsigned)(B * Hq)), dim3(256), 0, (hipStream_t)stream, p);
     SDAG_HIP_CHECK(hipGetLastError());
     return SDAG_OK;
 }
