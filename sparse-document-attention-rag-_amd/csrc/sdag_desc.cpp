@@ -45,7 +45,10 @@ struct SchedUnit {
     int64_t lmask_base;    // word offset (from the start of the table the steps live in) of that sequence's lane masks
 };
 
-inline int64_t unit_cost(const SchedUnit& u) { return (u.item_end - u.item_begin) + 2; }
+// Cost of a unit in quarter steps: loading its Q rows and storing its O rows takes about as long as 1.25 tile steps
+// (measured: 1.1 to 1.3).
+inline int64_t unit_cost(const SchedUnit& u) { return 4 * (int64_t)(u.item_end - u.item_begin) + 5; }
+inline bool unit_is_long(const SchedUnit& u) { return u.item_end - u.item_begin >= 14; }
 
 // Deal the units, in the order given, to n_streams streams: each goes to the stream with the least work so far
 // (cost = key tiles + a fixed charge per unit for loading Q and storing O); with `half` given (one entry per unit,
@@ -64,6 +67,37 @@ void build_schedule(const std::vector<SchedUnit>& units, int n_streams, int32_t*
         mine[best].push_back((int32_t)u);
         load[best] += unit_cost(units[u]);
     }
+    // Dealt in an order that is not longest-first (the batch order above), the streams end up to one long unit
+    // apart.  Level each group of streams: move a unit from the most loaded stream to the least loaded one while
+    // that lowers the larger of the two, and keep every stream's units in dealing order.
+    if (half)
+        for (int g = 0; g < 2; ++g) {
+            const int lo = g ? n_streams / 2 : 0, hi = g ? n_streams : n_streams / 2;
+            for (int64_t round = 0; round < (int64_t)units.size(); ++round) {
+                int smax = lo, smin = lo;
+                for (int s = lo + 1; s < hi; ++s) {
+                    if (load[s] > load[smax]) smax = s;
+                    if (load[s] < load[smin]) smin = s;
+                }
+                const int64_t gap = load[smax] - load[smin];
+                // the unit whose cost is nearest to half the gap, among those smaller than the gap; the latest such
+                int pick = -1;
+                int64_t pick_err = 0;
+                for (int i = (int)mine[smax].size() - 1; i >= 0; --i) {
+                    const int64_t c = unit_cost(units[mine[smax][i]]);
+                    if (c >= gap) continue;
+                    const int64_t err = 2 * c > gap ? 2 * c - gap : gap - 2 * c;
+                    if (pick < 0 || err < pick_err) { pick = i; pick_err = err; }
+                }
+                if (pick < 0) break;
+                const int32_t ui = mine[smax][pick];
+                const int64_t c = unit_cost(units[ui]);
+                mine[smax].erase(mine[smax].begin() + pick);
+                mine[smin].insert(std::upper_bound(mine[smin].begin(), mine[smin].end(), ui), ui);
+                load[smax] -= c;
+                load[smin] += c;
+            }
+        }
     int64_t n = 0;
     for (int s = 0; s < n_streams; ++s) {
         stream_off[s] = (int32_t)n;
@@ -490,7 +524,7 @@ extern "C" int sdag_batch_build(const int32_t* const* descs, int B, int n_stream
         std::stable_sort(perm.begin(), perm.end(), [&](size_t x, size_t y) {
             if (su[x].b != su[y].b) return su[x].b < su[y].b;
             // (long units - rows that see most of the prompt - first: dealt last, they would unbalance the streams)
-            const bool lx = unit_cost(su[x]) >= 16, ly = unit_cost(su[y]) >= 16;
+            const bool lx = unit_is_long(su[x]), ly = unit_is_long(su[y]);
             if (lx != ly) return lx;
             return su[x].items[2 * (su[x].item_end - 1)] < su[y].items[2 * (su[y].item_end - 1)];
         });

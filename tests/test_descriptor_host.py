@@ -160,10 +160,14 @@ def test_batch_table_stream_halves():
     ends = {}  # (sequence, half of the streams) -> first keys of the last tiles of its units
     for s in range(ns):
         r = steps[so[s]: so[s + 1]]
-        cost[s] = len(r) + 2 * int((r[:, 2] & 1).sum())
+        cost[s] = 4 * len(r) + 5 * int((r[:, 2] & 1).sum())     # the builder's measure: a unit = 1.25 steps
         for st in r[(r[:, 2] & 2) != 0]:
             ends.setdefault((int(st[3]), s >= ns // 2), []).append(int(st[0]))
     for b in range(B):
         lo, hi = ends[(b, False)], ends[(b, True)]
         assert max(lo) <= min(hi) or max(hi) <= min(lo)          # the two halves split the sequence by key range
-    assert cost.max() <= 1.2 * cost.mean()
+    assert cost.max() <= 1.05 * cost.mean()                       # levelled inside each half
+    # ... and inside a stream the units stay in the order they were dealt in: sequence by sequence
+    for s in range(ns):
+        seqs = steps[so[s]: so[s + 1], 3]
+        assert (np.diff(seqs) >= 0).all()

@@ -4,7 +4,7 @@ masked steps): least-squares cost of a step / a unit / a mask, and the spread th
 Needs `make -C sparse-document-attention-rag-_amd/csrc wgtimes`; GPU only.  usage: attn_wg_times.py [n_streams]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["SDAG_HIP_LIB"] = os.path.join(ROOT, "tools/_wgtimes.so")
+os.environ["SDAG_HIP_LIB"] = os.path.join(ROOT, os.environ.get("WGTIMES_LIB", "tools/_wgtimes.so"))
 sys.path.insert(0, os.path.join(ROOT, "sparse-document-attention-rag-_amd")); sys.path.insert(0, ROOT)
 import numpy as np, torch, sdag_amd
 dev = torch.device("cuda:0")
