@@ -399,7 +399,12 @@ __global__ __launch_bounds__(256) void corpus_prepare_kernel(const float* __rest
         *reinterpret_cast<ushort4*>(C16 + row * d + j) = o;
     }
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-    if (lane == 0) atomicMax(max_norm_bits, __float_as_uint(sqrtf(ss) * 1.0001f));
+    // Rows of one corpus have nearly equal norms: after the first few, a plain read shows that the row changes
+    // nothing, and millions of atomics on one address (each a round trip to the L2) are avoided.
+    if (lane == 0) {
+        const unsigned bits = __float_as_uint(sqrtf(ss) * 1.0001f);
+        if (bits > __atomic_load_n(max_norm_bits, __ATOMIC_RELAXED)) atomicMax(max_norm_bits, bits);
+    }
 }
 
 // One block per query: collect the candidates, rescore them with the exact chain, write the best k.
