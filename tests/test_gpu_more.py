@@ -359,6 +359,35 @@ def test_attention_batch_with_stream_halves():
     assert _rel_err(o32, ref) <= 1e-3
 
 
+def test_attention_bench_batch_full_size():
+    """The benchmark's launch shape: 32 prompts of cfg 3 (L = 3100, one descriptor each) in one table with the default
+    stream count (64: split halves, levelled), two KV heads.  Same bits as one launch per sequence for fp32 and bf16
+    output; the oracle's values on the first and the last sequence."""
+    import sdag_amd
+    from oracle import sdag_ref
+
+    spans, qa, L = synthetic_layout(60, [300] * 10, 1, 30)
+    assert L == 3100
+    B, Hq, Hkv = 32, 8, 2
+    descs = [sdag_amd.from_spans(L, 60, spans, qa, None, max_items_per_unit=64) for _ in range(B)]
+    batch = sdag_amd.BatchDescriptor(descs)
+    assert int(batch.host[14]) == 64 and descs[0].n_units * B >= 8 * 64
+    g = torch.Generator().manual_seed(91)
+    q = torch.randn(B, L, Hq, 128, generator=g).to(torch.bfloat16).transpose(1, 2)
+    k = torch.randn(B, L, Hkv, 128, generator=g).to(torch.bfloat16).transpose(1, 2)
+    v = torch.randn(B, L, Hkv, 128, generator=g).to(torch.bfloat16).transpose(1, 2)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    for dt in (torch.float32, torch.bfloat16):
+        ob = sdag_amd.sdag_attention_batch(qd, kd, vd, batch, out_dtype=dt)
+        os_ = sdag_amd.sdag_attention(qd, kd, vd, descs[0], out_dtype=dt)
+        assert torch.equal(ob, os_), dt
+    mask = torch.from_numpy(sdag_ref.mask_from_spans(L, 60, spans, qa, None))
+    o32 = sdag_amd.sdag_attention_batch(qd, kd, vd, batch, out_dtype=torch.float32).cpu()
+    for b in (0, B - 1):
+        ref = sdag_ref.masked_attention(q[b:b + 1], k[b:b + 1], v[b:b + 1], mask, 128 ** -0.5)
+        assert _rel_err(o32[b:b + 1], ref) <= 1e-3, b
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
 def test_attention_random_layouts_streams_and_bf16_rows(seed):
     """Random ragged layouts (empty documents, out-of-range neighbour ids, overlapping spans), random stream
