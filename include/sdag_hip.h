@@ -113,7 +113,8 @@ int sdag_attn_fwd(const void* q, const void* k, const void* v, void* o,
  * sdag_batch_build concatenates B host descriptors (the same pointer may repeat) and deals their units, in
  * sequence-major order, to n_streams work streams (0 = 64; with eight or more units per stream, the units of a
  * sequence that end at its low keys go to the first half of the streams or to the second, the others to the other
- * half, so that the two halves share no K/V rows).  Tensors are padded to Lmax rows per sequence:
+ * half, so that the two halves share no K/V rows, and the streams of a half are then levelled to within one
+ * short unit of each other).  Tensors are padded to Lmax rows per sequence:
  * q [B, Hq, Lmax, D], k / v [B, Hkv, Lmax, D], o [B, Lmax, Hq, D] through the usual strides; rows at and
  * beyond a sequence's own length are neither read as queries nor written. */
 int sdag_batch_build(const int32_t* const* descs_host, int B, int n_streams, int32_t* out, int64_t cap_words,
