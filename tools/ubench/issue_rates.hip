@@ -28,7 +28,7 @@ __global__ __launch_bounds__(1024) void k(Out* out, int iters) {
     f32x4 ka = {a0, a1, a2, a3}, kb = {a4, a5, a6, a7};
     lds[threadIdx.x] = a0;
     unsigned la = (threadIdx.x & 63) * 16;
-    f32x4 r0 = {}, r1 = {};
+    f32x4 r0 = {}, r1 = {}, q0 = {}, q1 = {}, q2 = {}, q3 = {};
     f32x2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, d0 = {}, d1 = {};
     unsigned long long msk = 0x5555555555555555ull + blockIdx.x;
     __syncthreads();
@@ -106,11 +106,19 @@ __global__ __launch_bounds__(1024) void k(Out* out, int iters) {
         } else if constexpr (T == 18) {  // 16 x (MFMA + 4 exp)
             asm volatile(REP16("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n")
                          : "+v"(c0), "+v"(c1), "+v"(ka), "+v"(kb), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        } else if constexpr (T == 19) {  // 64 MFMA 16x16x32 bf16 on 4 chains: the flops of 32 MFMA 32x32x16
+            asm volatile(REP16("v_mfma_f32_16x16x32_bf16 %0, %4, %5, %0\n v_mfma_f32_16x16x32_bf16 %1, %4, %5, %1\n"
+                               "v_mfma_f32_16x16x32_bf16 %2, %4, %5, %2\n v_mfma_f32_16x16x32_bf16 %3, %4, %5, %3\n")
+                         : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(ka), "v"(kb));
+        } else if constexpr (T == 20) {  // 16 x (2 MFMA 16x16x32 + 8 fma): the flops and vector work of T == 11
+            asm volatile(REP16("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %6, %6, %6, %6\n v_fma_f32 %7, %7, %7, %7\n"
+                               "v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1\n v_fma_f32 %8, %8, %8, %8\n v_fma_f32 %9, %9, %9, %9\n v_fma_f32 %10, %10, %10, %10\n v_fma_f32 %11, %11, %11, %11\n")
+                         : "+v"(q0), "+v"(q1), "+v"(ka), "+v"(kb), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
         }
     }
     long long t1 = clock64();
     long long w1 = wall_clock64();
-    float sink = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + c0[0] + c1[1] + c2[2] + c3[3] + ka[0] + kb[1] + r0[0] + r1[1] + p0[0] + p1[1] + p2[0] + p3[1] + d0[0] + d1[1];
+    float sink = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + c0[0] + c1[1] + c2[2] + c3[3] + ka[0] + kb[1] + r0[0] + r1[1] + p0[0] + p1[1] + p2[0] + p3[1] + d0[0] + d1[1] + q0[0] + q1[1] + q2[2] + q3[3];
     if (sink == 12345.678f) lds[0] = sink;
     if ((threadIdx.x & 63) == 0) {
         out[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = {t1 - t0, w1 - w0};
@@ -135,12 +143,20 @@ void run(const char* name, int n_instr, int blocks) {
         // per SIMD: waves_per_simd waves each issued ITER * n_instr instructions in `cyc` cycles
         printf("%-34s blocks=%3d waves/SIMD=%d: %7.2f cycles per instr and wave, %6.2f per instr and SIMD, clock %.0f MHz\n", name, blocks,
                waves_per_simd, cyc / (ITER * (double)n_instr), cyc / (ITER * (double)n_instr * waves_per_simd), cyc / wall * 100.0);
+        printf("%-34s   wall ns per %d-instr iteration and wave: %.1f\n", "", n_instr, wall * 10.0 / ITER);
     }
     hipFree(d);
 }
 
 int main(int argc, char** argv) {
     const int blocks = argc > 1 ? atoi(argv[1]) : 1;
+    if (argc > 2) {  // MFMA shapes only: equal flops per line pair, compare cycles x clock
+        run<7>("mfma 32x32x16 bf16, 4 chains", 32, blocks);
+        run<19>("mfma 16x16x32 bf16 x2, 4 chains", 32, blocks);
+        run<11>("mfma 32x32x16 + 8 fma", 16, blocks);
+        run<20>("2 mfma 16x16x32 + 8 fma", 16, blocks);
+        return 0;
+    }
     run<0>("v_fma_f32", 32, blocks);
     run<17>("v_pk_fma_f32", 32, blocks);
     run<5>("v_pk_mul_f32", 32, blocks);
