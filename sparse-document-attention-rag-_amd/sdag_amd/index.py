@@ -21,6 +21,8 @@ MAX_K = 32
 
 def _as_f32_2d(x, name: str) -> np.ndarray:
     a = np.ascontiguousarray(x, dtype=np.float32)
+    if not a.flags.writeable:  # e.g. a slice of a read-only memory map: torch.from_numpy wants a writable array
+        a = a.copy()
     if a.ndim != 2:
         raise ValueError(f"{name} must be 2-D")
     return a
@@ -44,13 +46,37 @@ class FlatIPIndex:
         if self.device.type != "cuda":
             raise RuntimeError("FlatIPIndex lives on the GPU (no CPU fallback)")
         self.id_base = int(id_base)
-        self._corpus: Optional[torch.Tensor] = None  # [N, d] fp32
+        self._corpus: Optional[torch.Tensor] = None  # [N, d] fp32 (a view of _buf while a reservation is being filled)
+        self._buf: Optional[torch.Tensor] = None     # rows reserved ahead of add() (see reserve)
         self._ws: Optional[torch.Tensor] = None
+
+    @classmethod
+    def from_tensor(cls, corpus: torch.Tensor, id_base: int = 0, two_stage: bool = True) -> "FlatIPIndex":
+        """Index over rows that already live on the GPU (fp32 [N, d], contiguous): no copy is made, so several
+        indexes can cover row ranges of one resident corpus (shards)."""
+        if not corpus.is_cuda or corpus.dtype != torch.float32 or corpus.dim() != 2 or not corpus.is_contiguous():
+            raise ValueError("corpus must be a contiguous fp32 [N, d] tensor on the GPU")
+        idx = cls(corpus.shape[1], device=corpus.device, id_base=id_base, two_stage=two_stage)
+        idx._corpus = corpus
+        return idx
 
     # ---- faiss-like surface
     @property
     def ntotal(self) -> int:
         return 0 if self._corpus is None else int(self._corpus.shape[0])
+
+    def reserve(self, n_rows: int) -> None:
+        """Allocate room for ``n_rows`` rows once, so that a corpus loaded slice by slice is written in place instead
+        of being re-concatenated (and held twice) by every add()."""
+        n_rows = int(n_rows)
+        if n_rows <= (0 if self._buf is None else self._buf.shape[0]):
+            return
+        buf = torch.empty((n_rows, self.d), dtype=torch.float32, device=self.device)
+        n = self.ntotal
+        if n:
+            buf[:n] = self._corpus
+        self._buf = buf
+        self._corpus = buf[:n] if n else None
 
     def add(self, x) -> None:
         """Append rows (numpy on the host or a torch tensor on any device)."""
@@ -62,11 +88,17 @@ class FlatIPIndex:
             t = torch.from_numpy(_as_f32_2d(x, "x")).to(self.device)
         if t.shape[1] != self.d:
             raise ValueError(f"x has dimension {t.shape[1]}, index has {self.d}")
+        n = self.ntotal
+        if self._buf is not None and n + t.shape[0] <= self._buf.shape[0]:
+            self._buf[n:n + t.shape[0]] = t
+            self._corpus = self._buf[:n + t.shape[0]]
+            return
+        self._buf = None
         t = t.contiguous()
         self._corpus = t if self._corpus is None else torch.cat([self._corpus, t], dim=0)
 
     def reset(self) -> None:
-        self._corpus = None
+        self._corpus = self._buf = None
         self._c16 = self._c16_of = self._cmax = None
 
     def search(self, q, k: int) -> Tuple[np.ndarray, np.ndarray]:

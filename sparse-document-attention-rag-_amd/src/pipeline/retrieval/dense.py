@@ -41,9 +41,10 @@ def load_faiss_index_and_meta(index_path: str, meta_path: str, device: str | Non
     vecs = read_flat_vectors(index_path)
     dev = device or ("cuda:0" if str(_CFG_DEVICE).startswith("cuda") else str(_CFG_DEVICE))
     index = FlatIPIndex(vecs.shape[1], device=dev)
+    index.reserve(vecs.shape[0])  # N is known from the file header: one allocation, slices written in place
     step = 1 << 18
     for lo in range(0, vecs.shape[0], step):  # stream the (possibly memory-mapped) file in slices
-        index.add(np.ascontiguousarray(vecs[lo:lo + step]))
+        index.add(np.array(vecs[lo:lo + step], dtype=np.float32, order="C"))  # a writable copy of the mapped slice
     meta: List[Dict[str, Any]] = []
     with open(meta_path, "r", encoding="utf-8") as f:
         for line in f:

@@ -63,7 +63,8 @@ def build_blocked_causal_mask_full(base_seq_len: int, max_new_tokens: int, sys_u
     """Boolean [L, L] "row may attend column" tensor on ``device`` (SDAG.py:68-127).
 
     ``max_new_tokens`` is accepted and unused, as in the reference.  The returned tensor remembers the
-    descriptor it was expanded from, so ``generate_with_custom_mask`` does not have to re-derive it.
+    descriptor it was expanded from, so ``generate_with_custom_mask`` does not have to re-derive it from the
+    dense tensor (it checks that the tensor still holds what the descriptor says).
     """
     desc = sdag_amd.from_spans(base_seq_len, sys_user_len, [tuple(s) for s in doc_token_spans], qa_start, doc_neighbors)
     mask = desc.materialize(_gpu_device(device))
@@ -75,8 +76,13 @@ def build_blocked_causal_mask_full(base_seq_len: int, max_new_tokens: int, sys_u
 
 def _descriptor_of(prompt_mask: torch.Tensor, model_dtype: torch.dtype) -> Optional[sdag_amd.Descriptor]:
     desc = getattr(prompt_mask, "_sdag_desc", None)
-    if desc is not None and desc.L == prompt_mask.shape[0]:
-        return desc
+    if desc is not None and desc.L == prompt_mask.shape[0] and prompt_mask.dtype == torch.bool:
+        # The attribute survives in-place edits of the tensor (an ablation that clears a block, say), and the
+        # reference always honours the tensor's contents (SDAG.py:167-171): use the remembered descriptor only if
+        # it still expands to exactly this mask (one L x L comparison on the GPU).
+        dev = _gpu_device(prompt_mask.device)
+        if torch.equal(desc.materialize(dev), prompt_mask.to(dev)):
+            return desc
     if prompt_mask.dtype == torch.bool:
         return sdag_amd.from_dense(prompt_mask)
     # "pre-computed attention matrix" (SDAG.py:170-171): usable only if it is a 0 / very-negative additive mask

@@ -170,3 +170,51 @@ def make_bpe_tokenizer(seed=0, vocab=700):
         "{% for m in messages %}<|start_header_id|>{{ m['role'] }}<|end_header_id|>\n\n{{ m['content'] }}<|eot_id|>{% endfor %}"
         "{% if add_generation_prompt %}<|start_header_id|>assistant<|end_header_id|>\n\n{% endif %}")
     return fast, sentence
+
+
+class FakeRanker:
+    """Deterministic stand-in for the sentence encoder: unit vectors seeded by a hash of the text (the interface
+    the pipeline uses: ``encode(list, convert_to_tensor=True, normalize_embeddings=True)``)."""
+
+    def __init__(self, d=64, device="cpu"):
+        self.d, self.device = d, device
+
+    def get_sentence_embedding_dimension(self):
+        return self.d
+
+    def encode(self, texts, convert_to_tensor=True, normalize_embeddings=True, batch_size=32, **kw):
+        import torch
+
+        rows = []
+        for t in texts:
+            seed = int.from_bytes(hashlib.sha256(t.encode()).digest()[:4], "little")
+            v = np.random.default_rng(seed).standard_normal(self.d).astype(np.float32)
+            rows.append(v / np.linalg.norm(v))
+        out = torch.from_numpy(np.stack(rows)) if rows else torch.zeros((0, self.d))
+        return out.to(self.device)
+
+
+def load_e2e():
+    """The end-to-end fixture made by tests/golden/make_golden_e2e.py from the reference's own entry points:
+    (tokenizer rebuilt from its stored serialisation, fixture dict, path of the model weights)."""
+    from tokenizers import Tokenizer
+    from transformers import PreTrainedTokenizerFast
+
+    with open(os.path.join(GOLDEN, "e2e.json")) as f:
+        g = json.load(f)
+    tok = PreTrainedTokenizerFast(tokenizer_object=Tokenizer.from_str(g["tokenizer_json"]), bos_token=g["bos_token"],
+                                  eos_token=g["eos_token"])
+    tok.chat_template = g["chat_template"]
+    return tok, g, os.path.join(GOLDEN, "e2e_model.npz")
+
+
+def load_e2e_model(g, path, device="cpu", dtype=None):
+    import torch
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    z = np.load(path)
+    model = LlamaForCausalLM(LlamaConfig(**g["model_cfg"])).eval()
+    model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w::")})
+    if dtype is not None:
+        model = model.to(dtype)
+    return model.to(device), {k[8:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("logits::")}

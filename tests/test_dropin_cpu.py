@@ -136,6 +136,68 @@ def test_single_pass_spans_equal_prefix_tokenisations(SDAG):
     assert SDAG._prefix_token_counts(toy, "a b c d", [0, 3, 7]) == [len(toy("a b c d"[:c]).input_ids[0]) for c in (0, 3, 7)]
 
 
+def test_spans_equal_reference_function_outputs(SDAG):
+    """build_rag_chat_and_spans against what the REFERENCE's own function returned for the same inputs
+    (tests/golden/make_golden_e2e.py ran SDAG.py:216-304 with this tokenizer): prompt text, ranked documents and every
+    token position, over empty / whitespace / repeated documents, injected documents at one rank, past the end and at
+    two ranks, no documents, and a document that contains the question marker."""
+    import hashlib
+
+    from helpers import load_e2e
+
+    tok, g, _ = load_e2e()
+    assert SDAG._tokenizer_is_local(tok)                       # the single-tokenisation route is the one under test
+    for c in g["spans"] + g["e2e"]:
+        chat, sys_len, spans, qa, ranked = SDAG.build_rag_chat_and_spans(tok, g["system_prompt"], g["user_template"],
+                                                                         c["query"], c["mal"], c["docs"], c["rank"])
+        assert hashlib.sha256(chat.encode()).hexdigest() == c["chat_sha256"]
+        assert ranked == c["ranked_docs"]
+        assert (sys_len, [list(s) for s in spans], qa) == (c["sys_user_len"], c["spans"], c["qa_start"])
+    assert SDAG.SYSTEM_PROMPT_RAG == g["system_prompt"] and SDAG.USER_RAG_PROMPT == g["user_template"]
+
+
+def test_run_rag_with_doc_isolation_matches_reference_text(SDAG, monkeypatch):
+    """The public entry point end to end (spans -> document kNN -> descriptor -> prefill through the transformers
+    hook -> decode loop) against the text and first-step logits the REFERENCE's run_rag_with_doc_isolation
+    (SDAG.py:307-375) produced; on CPU the oracle stands in for the two GPU kernels (attention, Gram matrix)."""
+    from helpers import FakeRanker, load_e2e, load_e2e_model
+    from sdag_amd import hf_attention
+    import sdag_amd
+
+    tok, g, path = load_e2e()
+    model, first_logits = load_e2e_model(g, path)
+
+    def oracle_attention(q, k, v, desc, scaling=None, out_dtype=torch.bfloat16, out=None):
+        mask = torch.from_numpy(expand_descriptor(desc.host))
+        return sdag_ref.masked_attention(q.float(), k.float(), v.float(), mask, scaling)
+
+    def oracle_knn(emb, kept, n, k, device=None):
+        return sdag_ref.doc_knn_from_embeddings(emb.cpu().numpy(), kept, n, k)
+
+    monkeypatch.setattr(hf_attention, "sdag_attention", oracle_attention)
+    monkeypatch.setattr(hf_attention.torch, "bfloat16", torch.float32, raising=False)
+    monkeypatch.setattr(sdag_amd, "doc_knn", oracle_knn)
+    monkeypatch.setattr(SDAG, "TEMPERATURE", 0)
+    ranker = FakeRanker(g["ranker_dim"])
+    for c in g["e2e"]:
+        seen = {}
+        orig = model.forward
+
+        def spy(*a, **kw):
+            o = orig(*a, **kw)
+            seen.setdefault("logits", o.logits[0, -1, :].detach().clone())
+            return o
+
+        model.forward = spy
+        try:
+            text = SDAG.run_rag_with_doc_isolation(model, tok, c["query"], c["mal"], c["docs"], g["max_new_tokens"], "cpu",
+                                                   c["rank"], ranker, c["nbr_k"])
+        finally:
+            model.forward = orig
+        assert torch.allclose(seen["logits"], first_logits[c["name"]], atol=1e-4, rtol=1e-4), c["name"]
+        assert text == c["text"], c["name"]
+
+
 def test_ranked_list_injection_rules():
     from sdag_amd.ranked_list import inject_malicious_docs_into_ranked_list as inj
 

@@ -1,0 +1,203 @@
+"""GPU parity of the public entry points end to end, of the benchmark's head layout, and of the sharded search at
+the size of one shard of the 21 M-passage corpus."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import FakeRanker, load_e2e, load_e2e_model, synthetic_layout
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel_err(o, ref):
+    num = (o - ref).abs().amax(dim=(0, 1, 3))
+    den = ref.abs().amax(dim=(0, 1, 3))
+    return float((num / den).max())
+
+
+def test_run_rag_with_doc_isolation_end_to_end():
+    """``run_rag_with_doc_isolation`` (the one function the reference's main.py imports) on the GPU against what the
+    REFERENCE's own function returned on CPU for the same inputs (tests/golden/make_golden_e2e.py): token spans,
+    first-step logits (tolerance: bf16 attention operands inside an fp32 model, 2e-2 of max |logit|; the reference's
+    smallest winning margin in these cases is 2.9e-2) and the greedy text, with the ranker's embeddings on either
+    device, neighbours 0 / 1 / 2, an injected document and an empty one."""
+    SDAG = importlib.import_module("src.pipeline.sparse_attention_RAG.SDAG")
+    from sdag_amd import hf_attention
+
+    tok, g, path = load_e2e()
+    model, first_logits = load_e2e_model(g, path, device=DEV)
+    old_t = SDAG.TEMPERATURE
+    SDAG.TEMPERATURE = 0
+    calls = {"prefill": 0, "decode": 0}
+    real_prefill, real_decode = hf_attention.sdag_attention, hf_attention.decode_attention
+
+    def counting_prefill(*a, **kw):
+        calls["prefill"] += 1
+        return real_prefill(*a, **kw)
+
+    def counting_decode(*a, **kw):
+        calls["decode"] += 1
+        return real_decode(*a, **kw)
+
+    hf_attention.sdag_attention, hf_attention.decode_attention = counting_prefill, counting_decode
+    try:
+        for n, c in enumerate(g["e2e"]):
+            ranker = FakeRanker(g["ranker_dim"], device=DEV if n % 2 else "cpu")
+            chat, sys_len, spans, qa, ranked = SDAG.build_rag_chat_and_spans(
+                tok, g["system_prompt"], g["user_template"], c["query"], c["mal"], c["docs"], c["rank"])
+            assert (sys_len, [list(s) for s in spans], qa, ranked) == (c["sys_user_len"], c["spans"], c["qa_start"], c["ranked_docs"])
+            if c["nbr_k"] > 0:
+                assert SDAG.compute_doc_knn_for_docs(ranker, ranked, c["nbr_k"]) == c["neighbors"]
+            seen = {}
+            orig = model.forward
+
+            def spy(*a, **kw):
+                o = orig(*a, **kw)
+                seen.setdefault("logits", o.logits[0, -1, :].detach().float().cpu())
+                return o
+
+            model.forward = spy
+            calls["prefill"] = calls["decode"] = 0
+            try:
+                text = SDAG.run_rag_with_doc_isolation(model, tok, c["query"], c["mal"], c["docs"], g["max_new_tokens"], DEV,
+                                                       c["rank"], ranker, c["nbr_k"])
+            finally:
+                model.forward = orig
+            nl = g["model_cfg"]["num_hidden_layers"]
+            assert calls["prefill"] == nl and calls["decode"] > 0 and calls["decode"] % nl == 0   # both kernels ran
+            ref = first_logits[c["name"]]
+            assert float((seen["logits"] - ref).abs().max()) <= 2e-2 * float(ref.abs().max()), c["name"]
+            assert text == c["text"], c["name"]
+    finally:
+        hf_attention.sdag_attention, hf_attention.decode_attention = real_prefill, real_decode
+        SDAG.TEMPERATURE = old_t
+
+
+def test_mask_edited_in_place_is_honoured():
+    """A mask from build_blocked_causal_mask_full that the caller edits in place afterwards: the prefill must follow
+    the tensor's contents (SDAG.py:167-171), not the descriptor the tensor was expanded from."""
+    SDAG = importlib.import_module("src.pipeline.sparse_attention_RAG.SDAG")
+    import sdag_amd
+
+    spans, qa, L = synthetic_layout(9, [40, 30, 50], 1, 12)
+    mask = SDAG.build_blocked_causal_mask_full(L, 500, 9, spans, qa, device=DEV)
+    d0 = SDAG._descriptor_of(mask, torch.bfloat16)
+    assert d0 is mask._sdag_desc                                      # untouched: the remembered descriptor is used
+    mask[qa:, spans[1][0]:spans[1][1]] = False                        # the question no longer sees document 1
+    d1 = SDAG._descriptor_of(mask, torch.bfloat16)
+    assert d1 is not d0
+    assert torch.equal(d1.materialize(DEV), mask)
+    assert d1.allowed_pairs == d0.allowed_pairs - (L - qa) * (spans[1][1] - spans[1][0])
+    assert isinstance(d1, sdag_amd.Descriptor)
+
+
+def test_attention_benchmark_head_layout():
+    """The benchmark's head layout (32 query heads, 8 key/value heads: eight head slots per work stream) at
+    L = 3100: a single-sequence launch and a two-sequence batch launch (the second sequence ragged, document lengths
+    200-400) against the fp32 oracle, 1e-3 of max |ref| per head; bf16 output = rounding of the fp32 output."""
+    import sdag_amd
+    from oracle import sdag_ref
+
+    Hq, Hkv = 32, 8
+    spans, qa, L = synthetic_layout(60, [300] * 10, 1, 30)
+    assert L == 3100
+    lens = [int(x) for x in np.random.default_rng(2).integers(200, 401, size=10)]
+    spans2, qa2, L2 = synthetic_layout(60, lens, 1, 30)
+    Lmax = max(L, L2)
+    g = torch.Generator().manual_seed(404)
+    q = torch.randn(2, Lmax, Hq, 128, generator=g).to(torch.bfloat16).transpose(1, 2)
+    k = torch.randn(2, Lmax, Hkv, 128, generator=g).to(torch.bfloat16).transpose(1, 2)
+    v = torch.randn(2, Lmax, Hkv, 128, generator=g).to(torch.bfloat16).transpose(1, 2)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    d1 = sdag_amd.from_spans(L, 60, spans, qa, None)
+    d2 = sdag_amd.from_spans(L2, 60, spans2, qa2, None)
+    refs = []
+    for b, (Lb, sp, qb) in enumerate(((L, spans, qa), (L2, spans2, qa2))):
+        mask = torch.from_numpy(sdag_ref.mask_from_spans(Lb, 60, sp, qb, None))
+        refs.append(sdag_ref.masked_attention(q[b:b + 1, :, :Lb], k[b:b + 1, :, :Lb], v[b:b + 1, :, :Lb], mask, 128 ** -0.5))
+    o1 = sdag_amd.sdag_attention(qd[:1, :, :L], kd[:1, :, :L], vd[:1, :, :L], d1, out_dtype=torch.float32).cpu()
+    assert _rel_err(o1, refs[0]) <= 1e-3
+    ob = sdag_amd.sdag_attention(qd[:1, :, :L], kd[:1, :, :L], vd[:1, :, :L], d1).cpu()
+    assert torch.equal(ob, o1.to(torch.bfloat16))
+    batch = sdag_amd.BatchDescriptor([sdag_amd.from_spans(L, 60, spans, qa, None, max_items_per_unit=64),
+                                      sdag_amd.from_spans(L2, 60, spans2, qa2, None, max_items_per_unit=64)])
+    o2 = sdag_amd.sdag_attention_batch(qd, kd, vd, batch, out_dtype=torch.float32).cpu()
+    assert _rel_err(o2[:1, :L], refs[0]) <= 1e-3 and _rel_err(o2[1:, :L2], refs[1]) <= 1e-3
+    assert d2.n_uniform_rows == 10
+
+
+def _unit_corpus(n, d, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    out = torch.empty((n, d), dtype=torch.float32, device=DEV)
+    for lo in range(0, n, 1 << 18):
+        hi = min(n, lo + (1 << 18))
+        x = torch.randn((hi - lo, d), generator=g, device=DEV)
+        out[lo:hi] = x / x.norm(dim=1, keepdim=True)
+    return out
+
+
+def test_sharded_index_on_rccl_and_8_way_split_of_21m_corpus():
+    """The sharded search on the HIP path at the size of the 21 M-passage corpus (21,015,324 x 1024 fp32 = 86 GB
+    resident, + 43 GB bf16 copy):
+    (a) the 8-way split (shards of 2,626,916 rows, id_base = rank * ceil(N / 8)): every shard searched on its own, the
+        eight partial lists merged by ``sdag_topk_merge`` -> ids and score bits equal to ONE search over the whole
+        corpus; the scores of the returned rows are the oracle's, bit for bit;
+    (b) ``ShardedFlatIPIndex`` under a one-rank ``nccl`` (= RCCL) process group: the real all_gather_into_tensor and
+        merge kernel of the product path, against the single index and the oracle."""
+    import torch.distributed as dist
+
+    import sdag_amd
+    from oracle import dense_ref
+
+    d, nq, k = 1024, 32, 10
+    N = 21_015_324
+    per = -(-N // 8)
+    assert per == 2_626_916
+    gq = torch.Generator(device=DEV).manual_seed(5)
+    Q = torch.randn((nq, d), generator=gq, device=DEV)
+    Q = Q / Q.norm(dim=1, keepdim=True)
+    Qh = Q.cpu().numpy()
+    C = _unit_corpus(N, d, seed=1000)
+    whole = sdag_amd.FlatIPIndex.from_tensor(C)
+    s, i = whole.search_device(Q, k)
+    assert not whole.last_search_fell_back()
+    sh_, ih = s.cpu().numpy(), i.cpu().numpy()
+    assert (ih >= 0).all() and (ih < N).all() and (np.diff(sh_, axis=1) <= 0).all()
+    rows = np.unique(ih)
+    sc = dense_ref.dense_scores(Qh, C[torch.from_numpy(rows).to(DEV)].cpu().numpy())               # [rows, nq]
+    pos = {int(x): n for n, x in enumerate(rows)}
+    exact = np.array([[sc[pos[int(x)], qi] for x in ih[qi]] for qi in range(nq)], dtype=np.float32)
+    assert np.array_equal(exact.view(np.uint32), sh_.view(np.uint32))
+    del whole
+    parts = []
+    for r in range(8):
+        lo, hi = sdag_amd.shard_bounds(N, 8, r)
+        assert lo == r * per and hi == min(N, lo + per)
+        idx = sdag_amd.FlatIPIndex.from_tensor(C[lo:hi], id_base=lo)
+        ps, pi = idx.search_device(Q, k)
+        assert int(pi.min()) >= lo and int(pi.max()) < hi
+        parts.append((ps, pi))
+        del idx
+    ms, mi = sdag_amd.merge_partial_topk(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), k)
+    assert torch.equal(mi, i) and torch.equal(ms, s)
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29653")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        Csub = C[: 1 << 18]
+        shd = sdag_amd.ShardedFlatIPIndex(d, Csub.shape[0], DEV)
+        shd.add_local(Csub)
+        s1, i1 = shd.search_device(Q, k)
+        s0, i0 = sdag_amd.FlatIPIndex.from_tensor(Csub).search_device(Q, k)
+        assert torch.equal(i1, i0) and torch.equal(s1, s0)
+        gs, gi = dense_ref.dense_topk(Qh, Csub.cpu().numpy(), k)
+        assert np.array_equal(i1.cpu().numpy(), gi) and np.array_equal(s1.cpu().numpy().view(np.uint32), gs.view(np.uint32))
+    finally:
+        dist.destroy_process_group()
+    del C
+    torch.cuda.empty_cache()
