@@ -207,6 +207,13 @@ int sdag_gram(const float* E, int n, int d, float* sims, void* stream);
 int sdag_centroid_sims(const float* R, int nr, const float* Cand, int nc, int d, float* centroid,
                        float* sims, void* stream);
 
+/* sdag_centroid_sims for all queries of a retrieval batch in one launch: what select_malicious_docs_for_batch
+ * (malicious_selection.py:140-180) computes query by query.  Query b owns rows r_off[b] .. r_off[b+1] of R (at
+ * least one) and candidates c_off[b] .. c_off[b+1] of Cand; r_off / c_off: nb + 1 int32 offsets on the device.
+ * centroid [nb, d] and sims [c_off[nb]] on the device; the same bits as nb calls of sdag_centroid_sims. */
+int sdag_centroid_sims_batch(const float* R, const int32_t* r_off, const float* Cand, const int32_t* c_off, int nb, int d,
+                             float* centroid, float* sims, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

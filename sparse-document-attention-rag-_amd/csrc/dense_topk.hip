@@ -520,6 +520,29 @@ __global__ void centroid_sims_kernel(const float* __restrict__ Cand, int nc, int
     sims[c] = s;
 }
 
+// The two kernels above for a whole batch of queries in one launch: block b owns query b (rows r_off[b] .. r_off[b+1]
+// of R, candidates c_off[b] .. c_off[b+1] of Cand); same summation order per element, so the same bits.
+__global__ __launch_bounds__(256) void centroid_batch_kernel(const float* __restrict__ R, const int* __restrict__ r_off,
+                                                             const float* __restrict__ Cand, const int* __restrict__ c_off, int d,
+                                                             float* __restrict__ centroid, float* __restrict__ sims) {
+    const int b = blockIdx.x;
+    const int r0 = r_off[b], nr = r_off[b + 1] - r0;
+    const int c0 = c_off[b], nc = c_off[b + 1] - c0;
+    float* cen = centroid + (int64_t)b * d;
+    for (int j = threadIdx.x; j < d; j += 256) {
+        float s = 0.f;
+        for (int i = 0; i < nr; ++i) s += R[(int64_t)(r0 + i) * d + j];
+        cen[j] = s / (float)nr;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int c = threadIdx.x; c < nc; c += 256) {
+        float s = 0.f;
+        for (int j = 0; j < d; ++j) s = __builtin_fmaf(Cand[(int64_t)(c0 + c) * d + j], cen[j], s);
+        sims[c0 + c] = s;
+    }
+}
+
 struct ScanPlan { int n_wg; int rows_per_wg; };
 inline ScanPlan plan_scan(int64_t N) {
     int64_t tiles = (N + TR - 1) / TR;
@@ -712,5 +735,15 @@ extern "C" int sdag_centroid_sims(const float* R, int nr, const float* Cand, int
         hipLaunchKernelGGL(centroid_sims_kernel, dim3((nc + 63) / 64), dim3(64), 0, st, Cand, nc, d, centroid, sims);
         SDAG_HIP_CHECK(hipGetLastError());
     }
+    return SDAG_OK;
+}
+
+extern "C" int sdag_centroid_sims_batch(const float* R, const int32_t* r_off, const float* Cand, const int32_t* c_off, int nb, int d,
+                                        float* centroid, float* sims, void* stream) {
+    if (nb < 0 || d <= 0) return fail(SDAG_ERR_ARG, "bad nb or d");
+    if (nb == 0) return SDAG_OK;
+    if (!R || !r_off || !Cand || !c_off || !centroid || !sims) return fail(SDAG_ERR_ARG, "NULL pointer");
+    hipLaunchKernelGGL(centroid_batch_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, R, r_off, Cand, c_off, d, centroid, sims);
+    SDAG_HIP_CHECK(hipGetLastError());
     return SDAG_OK;
 }

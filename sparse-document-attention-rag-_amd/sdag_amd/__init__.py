@@ -8,9 +8,9 @@ from ._lib import SdagError, build
 from .attention import BoundAttention, BoundBatchAttention, decode_attention, sdag_attention, sdag_attention_batch
 from .descriptor import BatchDescriptor, Descriptor, from_dense, from_spans
 from .index import FlatIPIndex, ShardedFlatIPIndex, merge_partial_topk, shard_bounds
-from .ops import centroid_sims, doc_knn, gram
+from .ops import centroid_sims, centroid_sims_batch, doc_knn, gram
 
 __all__ = [
     "SdagError", "build", "sdag_attention", "decode_attention", "BoundAttention", "BoundBatchAttention", "sdag_attention_batch", "BatchDescriptor", "Descriptor", "from_dense", "from_spans", "FlatIPIndex",
-    "ShardedFlatIPIndex", "merge_partial_topk", "shard_bounds", "centroid_sims", "doc_knn", "gram",
+    "ShardedFlatIPIndex", "merge_partial_topk", "shard_bounds", "centroid_sims", "centroid_sims_batch", "doc_knn", "gram",
 ]

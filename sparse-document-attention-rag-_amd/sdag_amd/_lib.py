@@ -54,6 +54,7 @@ SIGNATURES = {
     "sdag_dense_topk2": (i32, [vp, i32, vp, vp, vp, i64, i32, i32, vp, vp, i64, vp, i64, vp]),
     "sdag_gram": (i32, [vp, i32, i32, vp, vp]),
     "sdag_centroid_sims": (i32, [vp, i32, vp, i32, i32, vp, vp, vp]),
+    "sdag_centroid_sims_batch": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
 }
 
 _lib = None

@@ -9,6 +9,7 @@ shared by every layer and head.
 from __future__ import annotations
 
 import ctypes
+import threading
 from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
@@ -20,7 +21,7 @@ H_L, H_NRB, H_NKT, H_NUNITS, H_NITEMS, H_NMASKS, H_NSPLIT, H_NUNIFORM = 2, 3, 4,
 H_NSLOTS = 17
 H_NSTREAMS = 20
 
-_scratch = np.empty(1 << 16, dtype=np.int32)
+_tls = threading.local()  # per-thread build buffer: descriptors may be built on a helper thread while the GPU runs
 
 
 class Descriptor:
@@ -96,15 +97,24 @@ class Descriptor:
         return out.view(torch.bool)
 
 
-def _run_builder(call) -> np.ndarray:
-    global _scratch
+def _run_builder(call, out: Optional[np.ndarray] = None) -> np.ndarray:
+    """Run a C builder into this thread's scratch buffer and return a copy of the words it wrote, or build straight
+    into ``out`` (a caller-owned int32 array, e.g. a view of pinned memory) and return the view of what was written."""
     need = ctypes.c_int64(0)
-    rc = call(_scratch.ctypes.data, _scratch.size, ctypes.byref(need))
+    if out is not None:
+        if out.dtype != np.int32 or not out.flags.c_contiguous or not out.flags.writeable:
+            raise ValueError("out must be a writable contiguous int32 array")
+        _lib.check(call(out.ctypes.data, out.size, ctypes.byref(need)))
+        return out[: int(need.value)]
+    scratch = getattr(_tls, "scratch", None)
+    if scratch is None:
+        scratch = _tls.scratch = np.empty(1 << 16, dtype=np.int32)
+    rc = call(scratch.ctypes.data, scratch.size, ctypes.byref(need))
     if rc == _lib.SDAG_ERR_CAPACITY:
-        _scratch = np.empty(int(need.value) * 2, dtype=np.int32)
-        rc = call(_scratch.ctypes.data, _scratch.size, ctypes.byref(need))
+        scratch = _tls.scratch = np.empty(int(need.value) * 2, dtype=np.int32)
+        rc = call(scratch.ctypes.data, scratch.size, ctypes.byref(need))
     _lib.check(rc)
-    return _scratch[: int(need.value)].copy()
+    return scratch[: int(need.value)].copy()
 
 
 def from_spans(
@@ -175,7 +185,9 @@ def from_dense(mask, max_items_per_unit: int = 0, n_streams: int = 0) -> Descrip
 class BatchDescriptor:
     """Descriptors of several sequences packed for one launch (``sdag_attn_fwd_batch``)."""
 
-    def __init__(self, descs: Sequence[Descriptor], n_streams: int = 0):
+    def __init__(self, descs: Sequence[Descriptor], n_streams: int = 0, out: Optional[np.ndarray] = None):
+        """``out``: build the table straight into this int32 array (pinned host memory for an asynchronous upload;
+        SdagError with code SDAG_ERR_CAPACITY if it is too small) instead of into memory of its own."""
         if not descs:
             raise ValueError("empty batch")
         self.descs = list(descs)
@@ -185,7 +197,7 @@ class BatchDescriptor:
         def call(out_ptr, cap, need):
             return lib.sdag_batch_build(ptrs, len(descs), int(n_streams), out_ptr, cap, need)
 
-        self.host = _run_builder(call)
+        self.host = _run_builder(call, out)
         self._dev: Dict[torch.device, torch.Tensor] = {}
         self.B = len(descs)
         self.Lmax = max(d.L for d in descs)
@@ -203,6 +215,13 @@ class BatchDescriptor:
             t = torch.from_numpy(self.host).to(device)
             self._dev[device] = t
         return t
+
+    def bind_device_copy(self, tensor: torch.Tensor) -> None:
+        """Adopt ``tensor`` (int32, on a GPU, holding a copy of ``host`` that the caller uploaded, e.g. asynchronously
+        from pinned memory on a side stream) as this table's device copy."""
+        if tensor.dtype != torch.int32 or not tensor.is_cuda or tensor.numel() < self.host.size:
+            raise ValueError("device copy must be an int32 GPU tensor of at least host.size words")
+        self._dev[tensor.device] = tensor
 
     def workspace_bytes(self, Hq: int, Hkv: int) -> int:
         n = _lib.lib().sdag_attn_batch_workspace_bytes(self.host_ptr, Hq, Hkv)

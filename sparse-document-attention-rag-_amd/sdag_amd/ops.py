@@ -55,3 +55,34 @@ def centroid_sims(retrieved_emb, candidate_emb, device="cuda:0") -> torch.Tensor
                                                  centroid.data_ptr(), sims.data_ptr() if nc else None,
                                                  _lib.stream_ptr(r.device)))
     return sims
+
+
+def centroid_sims_batch(retrieved_embs: Sequence, candidate_embs: Sequence, device="cuda:0") -> List[np.ndarray]:
+    """``centroid_sims`` for every query of a batch in ONE launch and one copy back to the host: query b has
+    ``retrieved_embs[b]`` [nr_b >= 1, d] and ``candidate_embs[b]`` [nc_b, d]; returns one fp32 array [nc_b] per query
+    (the same bits as per-query calls)."""
+    nb = len(retrieved_embs)
+    if nb != len(candidate_embs):
+        raise ValueError("one candidate set per query expected")
+    if nb == 0:
+        return []
+    rs = [_dev_f32(r, device) for r in retrieved_embs]
+    cs = [_dev_f32(c, device) for c in candidate_embs]
+    d = rs[0].shape[1]
+    if any(r.dim() != 2 or r.shape[0] < 1 or r.shape[1] != d for r in rs) or any(c.dim() != 2 or c.shape[1] != d for c in cs):
+        raise ValueError("embeddings must be [n, d] with the same d and at least one retrieved row per query")
+    dev = rs[0].device
+    r_off = np.zeros(nb + 1, dtype=np.int32)
+    c_off = np.zeros(nb + 1, dtype=np.int32)
+    r_off[1:] = np.cumsum([r.shape[0] for r in rs])
+    c_off[1:] = np.cumsum([c.shape[0] for c in cs])
+    R = torch.cat(rs, dim=0)
+    C = torch.cat(cs, dim=0) if int(c_off[-1]) else torch.zeros((1, d), dtype=torch.float32, device=dev)
+    offs = torch.from_numpy(np.concatenate([r_off, c_off])).to(dev)
+    centroid = torch.empty((nb, d), dtype=torch.float32, device=dev)
+    sims = torch.empty(max(int(c_off[-1]), 1), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().sdag_centroid_sims_batch(R.data_ptr(), offs.data_ptr(), C.data_ptr(), offs[nb + 1:].data_ptr(), nb, d,
+                                                       centroid.data_ptr(), sims.data_ptr(), _lib.stream_ptr(dev)))
+    host = sims.cpu().numpy()
+    return [host[c_off[b]:c_off[b + 1]].copy() for b in range(nb)]

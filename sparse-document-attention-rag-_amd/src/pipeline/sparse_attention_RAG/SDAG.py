@@ -142,16 +142,15 @@ def _n_tokens(tokenizer, text: str) -> int:
 
 
 _TAIL_MARGIN = 8  # characters re-tokenised in front of a cut (the longest look-ahead of the split patterns is 3)
-_local_cache: dict = {}
 
 
 def _tokenizer_is_local(tokenizer) -> bool:
     """True for fast tokenizers whose text -> token map is a left-to-right scan without look-behind: no
     normaliser, a split-pattern / byte-level pre-tokeniser that adds no prefix space, BPE inside the pre-tokens
     (the Llama-3 family).  Only those may count prefix lengths from one tokenisation of the whole prompt."""
-    key = id(tokenizer)
-    if key in _local_cache:
-        return _local_cache[key]
+    cached = getattr(tokenizer, "_sdag_is_local", None)  # kept on the object itself: an id() can be reused after GC
+    if cached is not None:
+        return cached
     ok = False
     try:
         if getattr(tokenizer, "is_fast", False):
@@ -168,7 +167,10 @@ def _tokenizer_is_local(tokenizer) -> bool:
                           for p_ in parts if p_.get("type") == "Split"))
     except Exception:
         ok = False
-    _local_cache[key] = ok
+    try:
+        tokenizer._sdag_is_local = ok
+    except Exception:  # an object that refuses attributes: decide again next time
+        pass
     return ok
 
 

@@ -263,6 +263,16 @@ def gen_small_ops():
         for n in (1, 2, 3, 5, 9):
             ref = REF_SEL._select_malicious_docs_for_query(rk, retrieved, cands, strategy, n)
             sel.append(dict(retrieved=retrieved, cands=cands, strategy=strategy, max_docs=n, out=ref))
+    # the batch routine (malicious_selection.py:140-180) with queries that fall back to the random module in between
+    sel_batch = []
+    r_batch = [retrieved, [], [f"other passage {i}" for i in range(4)], ["", "  "], [f"third set {i}" for i in range(7)]]
+    c_batch = [cands, cands[:3], [], cands[1:], [f"alt candidate {i}" for i in range(6)]]
+    for strategy in ("closest_to_centroid", "furthest_from_centroid", "random", "no_such_strategy"):
+        for n in (1, 2, 4, -1):
+            random.seed(1000 + n)
+            ref = REF_SEL.select_malicious_docs_for_batch(rk, r_batch, c_batch, strategy, n)
+            sel_batch.append(dict(seed=1000 + n, retrieved=r_batch, cands=c_batch, strategy=strategy, max_docs=n, out=ref,
+                                  next_random=random.random()))
     meta = [{"id": 10 + i, "text": f"text {i}"} for i in range(5)] + [{"text": "no id"}, {"id": "x"}]
     idx = [[0, 3, -1, 6], [5, 7, 100, 2]]
     sc = [[0.9, 0.5, -3.4e38, 0.1], [0.8, 0.7, 0.6, 0.5]]
@@ -276,7 +286,7 @@ def gen_small_ops():
 
     ind, scs = REF_DENSE.search_index(FakeIndex(), np.ones((2, 4), np.float64), 3)
     with open(os.path.join(HERE, "small_ops.json"), "w") as f:
-        json.dump(dict(ranker_dim=rk.d, knn=knn, select=sel,
+        json.dump(dict(ranker_dim=rk.d, knn=knn, select=sel, select_batch=sel_batch,
                        hits=dict(meta=meta, idx=idx, sc=sc, out=[list(x) for x in hits]),
                        search_index_order=dict(first_is_indices=bool(ind.dtype == np.int64), second_is_scores=bool(scs.dtype == np.float32))), f)
     print("small ops ok")

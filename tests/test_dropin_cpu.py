@@ -337,12 +337,15 @@ def test_overlay_on_reference_tree_when_present():
     code = (
         "import src.pipeline.retrieval.dense as d, src.pipeline.config as c, src.pipeline.sparse_attention_RAG.SDAG as S;"
         "import src.pipeline.models.datamodels as dm; from sdag_amd.datamodels import RetrievalBatch;"
-        "print(d.__file__); print(S.__file__); print(c.__file__); print(RetrievalBatch is dm.RetrievalBatch)")
+        "import src.pipeline.attack.malicious_selection as M, src.pipeline.attack.doc_corruption as DC;"
+        "print(d.__file__); print(S.__file__); print(c.__file__); print(RetrievalBatch is dm.RetrievalBatch);"
+        "print(M.__file__); print(DC.__file__)")
     env = dict(os.environ, PYTHONPATH=f"{pkg}:{ref}", PYTHONDONTWRITEBYTECODE="1")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd="/tmp", timeout=300)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().splitlines()
     assert lines[0].startswith(pkg) and lines[1].startswith(pkg) and lines[2].startswith(ref) and lines[3] == "True"
+    assert lines[4].startswith(pkg) and lines[5].startswith(ref)   # Near / Far selection here, the rest of attack/ there
 
 
 def _tie_groups(scores, payload):
@@ -399,3 +402,37 @@ def test_hybrid_rrf_fusion_matches_reference_outputs():
     rb = hyb.HybridRetriever(Fixed("d"), Fixed("s"), seed=3).retrieve_batch(["q1", "q2"], 5, 8)
     assert rb.q_embs == ["d", "d"] and all(len(x) == 5 for x in rb.ids_full)
     assert rb.ids_full[0][0] == "s0" and rb.ids_full[0][1] == "d0"      # equal scores: sparse ranking first
+
+
+def test_malicious_selection_overlay_matches_reference_outputs(monkeypatch):
+    """The Near / Far overlay module against what the REFERENCE's select_malicious_docs_for_batch and
+    _select_malicious_docs_for_query returned (tests/golden/make_golden.py), including the queries that fall back to
+    the ``random`` module: the picks and the state of the random generator afterwards must be the same.  On CPU the
+    oracle's centroid arithmetic stands in for the GPU kernel."""
+    import random
+
+    import sdag_amd
+    from helpers import FakeRanker
+
+    sel = importlib.import_module("src.pipeline.attack.malicious_selection")
+    with open(f"{GOLDEN}/small_ops.json") as f:
+        g = json.load(f)
+
+    def oracle_batch(rs, cs, device=None):
+        out = []
+        for r, c in zip(rs, cs):
+            cen = np.asarray(r, np.float32).mean(axis=0, keepdims=True)
+            out.append(np.matmul(np.asarray(c, np.float32), cen.T).reshape(-1))
+        return out
+
+    monkeypatch.setattr(sdag_amd, "centroid_sims_batch", oracle_batch)
+    rk = FakeRanker(g["ranker_dim"])
+    for c in g["select"]:
+        assert sel._select_malicious_docs_for_query(rk, c["retrieved"], c["cands"], c["strategy"], c["max_docs"]) == c["out"]
+    for c in g["select_batch"]:
+        random.seed(c["seed"])
+        out = sel.select_malicious_docs_for_batch(rk, c["retrieved"], c["cands"], c["strategy"], c["max_docs"])
+        assert out == c["out"], (c["strategy"], c["max_docs"])
+        assert random.random() == c["next_random"]
+    assert sel.encode_texts_with_ranker(rk, []).shape == (0, g["ranker_dim"])
+    assert sel.encode_texts_with_ranker(rk, ["a", "b"]).dtype == np.float32

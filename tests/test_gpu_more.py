@@ -199,6 +199,32 @@ def test_doc_knn_and_centroid_against_reference_outputs():
         assert [c["cands"][int(j)] for j in order[:n]] == c["out"]
 
 
+def test_malicious_selection_overlay_on_gpu():
+    """The Near / Far overlay module with the batched centroid kernel: picks equal to the reference's outputs (and
+    the random generator left in the same state), the batch launch bit-identical to per-query launches."""
+    import random
+
+    import sdag_amd
+    sel = importlib.import_module("src.pipeline.attack.malicious_selection")
+    with open(f"{GOLDEN}/small_ops.json") as f:
+        g = json.load(f)
+    for dev in ("cpu", DEV):
+        rk = FakeRanker(g["ranker_dim"], dev)
+        for c in g["select"]:
+            assert sel._select_malicious_docs_for_query(rk, c["retrieved"], c["cands"], c["strategy"], c["max_docs"]) == c["out"]
+        for c in g["select_batch"]:
+            random.seed(c["seed"])
+            assert sel.select_malicious_docs_for_batch(rk, c["retrieved"], c["cands"], c["strategy"], c["max_docs"]) == c["out"]
+            assert random.random() == c["next_random"]
+    rng = np.random.default_rng(8)
+    rs = [rng.standard_normal((n, 1024), dtype=np.float32) for n in (10, 1, 21, 7)]
+    cs = [rng.standard_normal((n, 1024), dtype=np.float32) for n in (5, 3, 0, 9)]
+    both = sdag_amd.centroid_sims_batch(rs, cs, device=DEV)
+    for r, c, b in zip(rs, cs, both):
+        one = sdag_amd.centroid_sims(r, c, device=DEV).cpu().numpy() if len(c) else np.zeros(0, np.float32)
+        assert np.array_equal(one.view(np.uint32), b.view(np.uint32))
+
+
 def test_dense_retriever_end_to_end(tmp_path):
     import sdag_amd
     from sdag_amd import index_io

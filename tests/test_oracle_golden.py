@@ -2,6 +2,7 @@
 import json
 
 import numpy as np
+import pytest
 import torch
 
 from helpers import GOLDEN, golden_bits, load_masks, mask_sha
@@ -105,3 +106,38 @@ def test_dense_oracle_definition():
     ms, mi = dense_ref.merge_topk(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]), 8)
     gs, gi = dense_ref.dense_topk(Q, C, 8)
     assert np.array_equal(mi, gi) and np.array_equal(ms, gs)
+
+
+@pytest.mark.parametrize("d,N", [(768, 200_000), (1024, 200_000)])
+def test_search_oracle_against_fp64_ranking(d, N):
+    """Independent cross-check of the search oracle's arithmetic (faiss, whose arithmetic the reference uses, is not
+    available to pin it): on random unit corpora the C oracle's fp32 FMA-chain scores must lie within the chain's
+    rounding bound d * 2^-24 * |q||c| of numpy's fp64 scores, its top-k SET must equal the fp64 top-k whenever the
+    fp64 gap between ranks k and k+1 exceeds twice that bound, and every position whose fp64 neighbours are both
+    further away than that must hold the same id.  The number of queries with a boundary gap under the bound is
+    printed: only for those could a different fp32 summation order (BLAS blocking) return a different set."""
+    from oracle import dense_ref
+
+    rng = np.random.default_rng(d)
+    C = rng.standard_normal((N, d), dtype=np.float32)
+    C /= np.linalg.norm(C, axis=1, keepdims=True)
+    Q = rng.standard_normal((32, d), dtype=np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    k = 10
+    s, i = dense_ref.dense_topk(Q, C, k)
+    S64 = Q.astype(np.float64) @ C.astype(np.float64).T
+    bound = d * 2.0 ** -24 * 1.0001          # |q| = |c| = 1 up to fp32 rounding of the normalisation
+    under = 0
+    for q in range(Q.shape[0]):
+        order = np.argsort(-S64[q], kind="stable")[: k + 1]
+        top = S64[q][order]
+        assert np.abs(s[q].astype(np.float64) - S64[q][i[q]]).max() <= bound
+        gaps = top[:-1] - top[1:]             # gaps[j] = score(rank j) - score(rank j + 1)
+        if gaps[k - 1] > 2 * bound:
+            assert set(i[q].tolist()) == set(order[:k].tolist())
+        else:
+            under += 1
+        for j in range(k):
+            if (j == 0 or gaps[j - 1] > 2 * bound) and gaps[j] > 2 * bound:
+                assert i[q][j] == order[j]
+    print(f"d={d} N={N}: {under} of {Q.shape[0]} queries have a k/(k+1) fp64 gap under {2 * bound:.2e}")
