@@ -105,6 +105,25 @@ int sdag_attn_fwd(const void* q, const void* k, const void* v, void* o,
                   const int32_t* desc_host, const int32_t* desc_dev,
                   void* workspace, int64_t workspace_bytes, int out_dtype, void* stream);
 
+/* sdag_attn_fwd for callers that cannot allocate device memory or carry a workspace: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference (which never manages
+ * device memory itself).  Same arguments and results as sdag_attn_fwd without the workspace: the scratch (partial
+ * results of split row blocks, column sums of V) lives in a device array that is part of the library's image,
+ * SDAG_STATIC_SCRATCH_BYTES per GPU, held until the process ends.  Returns SDAG_ERR_CAPACITY when
+ * sdag_attn_workspace_bytes(desc_host, B, Hq, Hkv) exceeds that size.  The call allocates and frees nothing.  All
+ * calls on one GPU share that GPU's array: calls that overlap in time on one GPU (different streams or threads)
+ * race; calls on one stream, or otherwise ordered, are safe.  Nothing in the array has to be cleared between calls:
+ * every word a call reads was written earlier by that same call. */
+#define SDAG_STATIC_SCRATCH_BYTES (8 << 20)
+
+int sdag_attn_fwd_static(const void* q, const void* k, const void* v, void* o,
+                         int64_t q_sb, int64_t q_sh, int64_t q_sl,
+                         int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                         int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                         int64_t o_sb, int64_t o_sl, int64_t o_sh,
+                         int B, int Hq, int Hkv, int L, int D, float scale,
+                         const int32_t* desc_host, const int32_t* desc_dev, int out_dtype, void* stream);
+
 /* Several sequences in one launch, each with its OWN descriptor (different prompts have different spans and
  * lengths).  The reference runs one query at a time (src/pipeline/main.py:469-496 calls
  * run_rag_with_doc_isolation per query); batching the masked prefill of many queries is how this build fills

@@ -27,7 +27,14 @@
 // per-chunk column sums that extra blocks of the main launch compute.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "common.h"
+
+// Scratch memory of sdag_attn_fwd_static (partial results of split row blocks and column sums of V): part of the
+// library's device image, so the entry point has nothing to allocate.  Each GPU holds its own copy at its own
+// address; in host code the name only stands for the symbol, the address comes from hipGetSymbolAddress.
+static __device__ __align__(256) unsigned char scratch[SDAG_STATIC_SCRATCH_BYTES];
 
 namespace sdag {
 #ifdef SDAG_WGTIMES
@@ -679,6 +686,47 @@ extern "C" int sdag_attn_fwd(const void* q, const void* k, const void* v, void* 
     p.slots_per_b = p.n_slots;
     return launch(p, t, B, Hq, Hkv, scale, out_dtype, desc_host[H_NSTEPS] ? (int64_t)p.n_streams * B : 0, (int64_t)p.n_slots * B,
                   (int64_t)desc_host[H_NSPLIT] * B, (int64_t)desc_host[H_NUNIFORM] * B, workspace, (hipStream_t)stream);
+}
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+void* g_scratch_ptr[MAX_DEVICES];  // address of `scratch` on each device, looked up on the first call there
+std::mutex g_scratch_mu;
+
+// Address of the current device's copy of `scratch`.
+int static_scratch(void** out) {
+    int dev = -1;
+    SDAG_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(SDAG_ERR_ARG, "device %d outside [0, %d)", dev, MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        SDAG_HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(SDAG_ERR_HIP, "hipGetSymbolAddress returned NULL");
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return SDAG_OK;
+}
+}  // namespace
+
+extern "C" int sdag_attn_fwd_static(const void* q, const void* k, const void* v, void* o,
+                                    int64_t q_sb, int64_t q_sh, int64_t q_sl,
+                                    int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                    int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                                    int64_t o_sb, int64_t o_sl, int64_t o_sh,
+                                    int B, int Hq, int Hkv, int L, int Dh, float scale,
+                                    const int32_t* desc_host, const int32_t* desc_dev, int out_dtype, void* stream) {
+    if (!desc_ok(desc_host)) return fail(SDAG_ERR_DESC, "desc_host is not a descriptor");
+    if (B <= 0 || Hq <= 0 || Hkv <= 0) return fail(SDAG_ERR_ARG, "bad B/Hq/Hkv/L");
+    const int64_t need = sdag_attn_workspace_bytes(desc_host, B, Hq, Hkv);
+    if (need > (int64_t)SDAG_STATIC_SCRATCH_BYTES)
+        return fail(SDAG_ERR_CAPACITY, "this call needs %lld bytes of scratch, sdag_attn_fwd_static holds %lld: use sdag_attn_fwd with a workspace",
+                    (long long)need, (long long)SDAG_STATIC_SCRATCH_BYTES);
+    void* ws = nullptr;
+    if (int rc = static_scratch(&ws)) return rc;
+    return sdag_attn_fwd(q, k, v, o, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sl, o_sh, B, Hq, Hkv, L, Dh, scale,
+                         desc_host, desc_dev, ws, (int64_t)SDAG_STATIC_SCRATCH_BYTES, out_dtype, stream);
 }
 
 extern "C" int64_t sdag_attn_batch_workspace_bytes(const int32_t* bt, int Hq, int Hkv) {

@@ -40,6 +40,7 @@ SIGNATURES = {
     "sdag_mask_materialize": (i32, [vp, vp, vp, vp]),
     "sdag_attn_workspace_bytes": (i64, [vp, i32, i32, i32]),
     "sdag_attn_fwd": (i32, [vp, vp, vp, vp] + [i64] * 12 + [i32] * 5 + [ctypes.c_float, vp, vp, vp, i64, i32, vp]),
+    "sdag_attn_fwd_static": (i32, [vp, vp, vp, vp] + [i64] * 12 + [i32] * 5 + [ctypes.c_float, vp, vp, i32, vp]),
     "sdag_batch_build": (i32, [vp, i32, i32, vp, i64, c_i64p]),
     "sdag_attn_batch_workspace_bytes": (i64, [vp, i32, i32]),
     "sdag_attn_fwd_batch": (i32, [vp, vp, vp, vp] + [i64] * 12 + [i32] * 5 + [ctypes.c_float, vp, vp, vp, i64, i32, vp]),
