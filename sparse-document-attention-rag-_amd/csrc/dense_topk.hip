@@ -348,20 +348,35 @@ __global__ __launch_bounds__(MRG_THREADS) void topk_merge_kernel(const float* __
 // exact score of the same row.  Then every row of the exact top k has an approximate score >= a_k - 2 eps, a_k being
 // the k-th best approximate score: the k rows with the best approximate scores have exact scores >= a_k - eps, so the
 // k-th best exact score is at least that, and a row that reaches it exactly is within eps of it approximately.
-// The candidate scan keeps the best k approximate scores per stripe (so a_k is known exactly); all entries
-// >= a_k - 2 eps are rescored with the exact fp32 chain and ranked.  A stripe whose k-th entry is itself a candidate
-// (it may have dropped one), or more candidates than fit, raise a flag, and the exact scan then runs for the batch (the flag is read on the device: no host round trip).
+// The candidate scan keeps the best ks approximate scores per stripe (ks = scan_keep(k) >= k: a margin, so that a
+// stripe holding several of the best rows does not look as if it had dropped one); the rescoring kernel takes every
+// entry >= LB - 2 eps with LB <= a_k (see there), scores it with the exact fp32 chain and ranks.  A stripe whose ks
+// entries are all candidates, or more candidates than fit, raise a flag, and the exact scan then runs for the batch
+// (the flag is read on the device: no host round trip).
 constexpr int RS_CMAX = 512;  // candidates per query the rescoring kernel holds
 constexpr int RS_DC = 128;    // dimensions per LDS chunk
-constexpr int RS_G = 64;      // candidates rescored per pass
 
 __host__ __device__ inline float eps_rel(int d) { return 0.0079f + (float)d * 1.2e-7f; }
 
-// One block per query: bf16 copy (round to nearest even) and eps = eps_rel(d) * |q| * cmax, rounded up.
+// Entries the candidate scan keeps per stripe and query for a search of the best k: k plus a margin of a quarter (at
+// least 2), never fewer than 8.  Every kept entry costs scan time (the running lists are filtered and compacted per
+// tile: about 12 us per entry at 2 M x 1024), so the margin is small; it decides how many near-ties of the best rows
+// one stripe may hold before the search has to fall back to the exact scan.
+inline int scan_keep(int k) {
+    int m = k + (k / 4 > 2 ? k / 4 : 2);
+    if (m < 8) m = 8;
+    return m < MAX_K ? m : MAX_K;
+}
+
+// One block per query: bf16 copy (round to nearest even) and eps = eps_rel(d) * |q| * cmax, rounded up.  Block 0 also
+// clears the fallback flags of the call's query batches (n_flags of them).
 __global__ __launch_bounds__(256) void query_prepare_kernel(const float* __restrict__ Q, int d, const float* __restrict__ cmax,
-                                                            unsigned short* __restrict__ Q16, float* __restrict__ eps) {
+                                                            unsigned short* __restrict__ Q16, float* __restrict__ eps,
+                                                            int* __restrict__ flags, int n_flags) {
     __shared__ float red[256];
     const int q = blockIdx.x, tid = threadIdx.x;
+    if (q == 0)
+        for (int f = tid; f < n_flags; f += 256) flags[f] = 0;
     float ss = 0.f;
     for (int j = tid; j < d; j += 256) {
         const float x = Q[(int64_t)q * d + j];
@@ -407,30 +422,60 @@ __global__ __launch_bounds__(256) void corpus_prepare_kernel(const float* __rest
     }
 }
 
-// One block per query: collect the candidates, rescore them with the exact chain, write the best k.
-__global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ Q, const float* __restrict__ C, int d, int k,
+// One block per query: find the candidates in the stripe lists, rescore them with the exact chain, write the best k.
+//
+// The stripe lists hold the best ks >= k approximate scores of every stripe, sorted best first.  Threshold: the k-th
+// largest of the stripes' maxima is a lower bound LB of a_k (they are scores of k distinct rows), so every row of the
+// exact top k has an approximate score >= LB - 2 eps; every list entry above that line is a candidate (a superset of
+// the set a_k itself would give: no separate merge of the lists is needed to know a_k).  A stripe whose ks entries are
+// ALL candidates may have dropped one, and more than RS_CMAX candidates do not fit: either raises the flag that makes
+// the exact scan run for the batch.
+constexpr int RS_G2 = 128;    // candidates rescored per pass
+constexpr int RS_LDS = RS_G2 * (RS_DC + 1) * 4;  // dynamic LDS of the rescoring kernel: the row chunk image
+
+__global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ Q, const float* __restrict__ C, int d, int k, int ks,
                                                       const float* __restrict__ part_s, const int* __restrict__ part_i, int n_wg,
-                                                      const float* __restrict__ approx_s, const float* __restrict__ eps,
-                                                      int64_t id_base, float* __restrict__ out_s, int64_t* __restrict__ out_i,
-                                                      int* __restrict__ flag) {
+                                                      const float* __restrict__ eps, int64_t id_base, float* __restrict__ out_s,
+                                                      int64_t* __restrict__ out_i, int* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];  // [RS_G2][RS_DC + 1]
     __shared__ int cand[RS_CMAX];
     __shared__ float ex[RS_CMAX];
-    __shared__ float rows[RS_G][RS_DC + 1];
+    __shared__ float mx[MAX_WG];
     __shared__ float qs[RS_DC];
+    __shared__ float lb_s;
     __shared__ int n_s, bad_s;
     const int q = blockIdx.x, tid = threadIdx.x;
-    if (tid == 0) { n_s = 0; bad_s = 0; }
+    if (tid == 0) { n_s = 0; bad_s = 0; lb_s = -INFINITY; }
+    // ---- the stripes' maxima, and LB = the k-th largest of them (by counting, ties by stripe index)
+    for (int p = tid; p < MAX_WG; p += 256) {
+        float v = -INFINITY;
+        if (p < n_wg) {
+            const int64_t src = ((int64_t)p * QT + q) * ks;
+            if (part_i[src] >= 0) v = part_s[src];
+        }
+        mx[p] = v;
+    }
     __syncthreads();
-    const float ak = approx_s[(int64_t)q * k + (k - 1)];
-    const float thr = ak == -FLT_MAX ? -INFINITY : ak - 2.0f * eps[q];   // fewer than k rows in all: take everything
-    for (int e = tid; e < n_wg * k; e += 256) {
-        const int part = e / k, t = e - part * k;
-        const int64_t src = ((int64_t)part * QT + q) * k + t;
-        const int id = part_i[src];
-        if (id < 0 || !(part_s[src] >= thr)) continue;
-        if (t == k - 1) bad_s = 1;  // the stripe's list is full of candidates: it may have dropped one
-        const int pos = atomicAdd(&n_s, 1);
-        if (pos < RS_CMAX) cand[pos] = id;
+    for (int p = tid; p < MAX_WG; p += 256) {
+        const float v = mx[p];
+        int rank = 0;
+        for (int j2 = 0; j2 < MAX_WG; ++j2) rank += (mx[j2] > v || (mx[j2] == v && j2 < p)) ? 1 : 0;
+        if (rank == k - 1) lb_s = v;  // -inf when fewer than k stripes hold a row: then everything is a candidate
+    }
+    __syncthreads();
+    const float thr = lb_s == -INFINITY ? -INFINITY : lb_s - 2.0f * eps[q];
+    // ---- candidates: only stripes whose maximum reaches the line are walked (their lists are sorted)
+    for (int p = tid; p < n_wg; p += 256) {
+        if (!(mx[p] >= thr)) continue;
+        const int64_t src = ((int64_t)p * QT + q) * ks;
+        int t = 0;
+        for (; t < ks; ++t) {
+            const int id = part_i[src + t];
+            if (id < 0 || !(part_s[src + t] >= thr)) break;
+            const int pos = atomicAdd(&n_s, 1);
+            if (pos < RS_CMAX) cand[pos] = id;
+        }
+        if (t == ks) bad_s = 1;  // the stripe's list is full of candidates: it may have dropped one
     }
     __syncthreads();
     int n = n_s;
@@ -438,21 +483,22 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
         n = RS_CMAX;
         if (tid == 0) bad_s = 1;
     }
-    // ---- exact scores: thread t < RS_G owns candidate g0 + t.  Rows and the query pass through LDS in chunks of
+    // ---- exact scores: thread t < RS_G2 owns candidate g0 + t.  Rows and the query pass through LDS in chunks of
     // RS_DC dimensions; the next chunk's pieces are already in flight (in registers) while a chunk is consumed.
     // Dimensions past d are staged as zeros: fma(0, 0, acc) leaves the chain's value unchanged.
-    constexpr int PIECES = RS_G * (RS_DC / 4) / 256;  // float4 pieces per thread and chunk
-    for (int g0 = 0; g0 < n; g0 += RS_G) {
+    constexpr int PIECES = RS_G2 * (RS_DC / 4) / 256;  // float4 pieces per thread and chunk
+    constexpr int RW = RS_DC + 1;
+    for (int g0 = 0; g0 < n; g0 += RS_G2) {
         float acc = 0.f;
         f32x4 pre[PIECES];
         float preq = 0.f;
         auto fetch = [&](int dc) {
 #pragma unroll
-            for (int i = 0; i < PIECES; ++i) {
-                const int e = tid + 256 * i;
+            for (int i2 = 0; i2 < PIECES; ++i2) {
+                const int e = tid + 256 * i2;
                 const int rr = e / (RS_DC / 4), c4 = e - rr * (RS_DC / 4);
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                pre[i] = (g0 + rr < n && dc + 4 * c4 < d) ? *reinterpret_cast<const f32x4*>(C + (int64_t)cand[g0 + rr] * d + dc + 4 * c4) : zero;
+                pre[i2] = (g0 + rr < n && dc + 4 * c4 < d) ? *reinterpret_cast<const f32x4*>(C + (int64_t)cand[g0 + rr] * d + dc + 4 * c4) : zero;
             }
             if (tid < RS_DC) preq = dc + tid < d ? Q[(int64_t)q * d + dc + tid] : 0.f;
         };
@@ -460,27 +506,29 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
         for (int dc = 0; dc < d; dc += RS_DC) {
             __syncthreads();  // the previous chunk has been consumed
 #pragma unroll
-            for (int i = 0; i < PIECES; ++i) {
-                const int e = tid + 256 * i;
+            for (int i2 = 0; i2 < PIECES; ++i2) {
+                const int e = tid + 256 * i2;
                 const int rr = e / (RS_DC / 4), c4 = e - rr * (RS_DC / 4);
-                rows[rr][4 * c4] = pre[i][0]; rows[rr][4 * c4 + 1] = pre[i][1]; rows[rr][4 * c4 + 2] = pre[i][2]; rows[rr][4 * c4 + 3] = pre[i][3];
+                float* rp = rows + rr * RW + 4 * c4;
+                rp[0] = pre[i2][0]; rp[1] = pre[i2][1]; rp[2] = pre[i2][2]; rp[3] = pre[i2][3];
             }
             if (tid < RS_DC) qs[tid] = preq;
             __syncthreads();
             if (dc + RS_DC < d) fetch(dc + RS_DC);
-            if (tid < RS_G && g0 + tid < n) {
+            if (tid < RS_G2 && g0 + tid < n) {
+                const float* rp = rows + tid * RW;
 #pragma unroll 32
-                for (int j = 0; j < RS_DC; ++j) acc = __builtin_fmaf(rows[tid][j], qs[j], acc);
+                for (int j2 = 0; j2 < RS_DC; ++j2) acc = __builtin_fmaf(rp[j2], qs[j2], acc);
             }
         }
-        if (tid < RS_G && g0 + tid < n) ex[g0 + tid] = acc;
+        if (tid < RS_G2 && g0 + tid < n) ex[g0 + tid] = acc;
     }
     __syncthreads();
     for (int c = tid; c < n; c += 256) {
         const float sc = ex[c];
         const int ic = cand[c];
         int rank = 0;
-        for (int j = 0; j < n; ++j) rank += better(ex[j], cand[j], sc, ic) ? 1 : 0;
+        for (int j2 = 0; j2 < n; ++j2) rank += better(ex[j2], cand[j2], sc, ic) ? 1 : 0;
         if (rank < k && sc == sc) {
             out_s[(int64_t)q * k + rank] = sc;
             out_i[(int64_t)q * k + rank] = (int64_t)ic + id_base;
@@ -615,17 +663,17 @@ extern "C" int sdag_corpus_to_bf16(const float* C, int64_t N, int d, void* C16, 
 }
 
 namespace {
-struct Ws2 { int64_t part_s, part_i, approx_s, approx_i, flag, eps, q16, exact, total; };
+struct Ws2 { int64_t part_s, part_i, flag, eps, q16, exact, total; int n_flags; };
 Ws2 plan_ws2(int nq, int64_t N, int d, int k) {
     const ScanPlan pl = plan_scan(N);
+    const int ks = scan_keep(k);
     Ws2 w;
     int64_t off = 0;
     auto take = [&](int64_t bytes) { const int64_t o = off; off += (bytes + 255) & ~255ll; return o; };
-    w.part_s = take((int64_t)pl.n_wg * QT * k * 4);
-    w.part_i = take((int64_t)pl.n_wg * QT * k * 4);
-    w.approx_s = take((int64_t)QT * k * 4);
-    w.approx_i = take((int64_t)QT * k * 8);
-    w.flag = take(4);
+    w.part_s = take((int64_t)pl.n_wg * QT * ks * 4);
+    w.part_i = take((int64_t)pl.n_wg * QT * ks * 4);
+    w.n_flags = (nq + QT - 1) / QT;  // one fallback flag per batch of QT queries
+    w.flag = take((int64_t)(w.n_flags > 0 ? w.n_flags : 1) * 4);
     w.eps = take((int64_t)nq * 4);
     w.q16 = take((int64_t)nq * d * 2);
     w.exact = take((int64_t)pl.n_wg * QT * k * 8);
@@ -641,7 +689,8 @@ extern "C" int64_t sdag_dense_topk2_workspace_bytes(int nq, int64_t N, int d, in
 
 extern "C" int64_t sdag_dense_topk2_flag_offset(int nq, int64_t N, int d, int k) {
     if (k <= 0 || k > MAX_K || N < 0 || nq < 0 || d <= 0) return -1;
-    return plan_ws2(nq, N, d, k).flag;
+    const Ws2 w = plan_ws2(nq, N, d, k);
+    return w.flag + (int64_t)(w.n_flags > 0 ? w.n_flags - 1 : 0) * 4;  // the last batch's flag
 }
 
 extern "C" int sdag_dense_topk2(const float* Q, int nq, const float* C, const void* C16, const float* max_row_norm, int64_t N,
@@ -661,33 +710,30 @@ extern "C" int sdag_dense_topk2(const float* Q, int nq, const float* C, const vo
     unsigned char* ws = (unsigned char*)workspace;
     float* part_s = (float*)(ws + w.part_s);
     int* part_i = (int*)(ws + w.part_i);
-    float* approx_s = (float*)(ws + w.approx_s);
-    int64_t* approx_i = (int64_t*)(ws + w.approx_i);
-    int* flag = (int*)(ws + w.flag);
+    int* flags = (int*)(ws + w.flag);
     float* eps = (float*)(ws + w.eps);
     unsigned short* q16 = (unsigned short*)(ws + w.q16);
     float* ex_s = (float*)(ws + w.exact);
     int* ex_i = (int*)(ex_s + (int64_t)pl.n_wg * QT * k);
+    const int ks = scan_keep(k);
     if ((((int64_t)pl.n_wg * k + 63) / 64) * k > MRG_A) return fail(SDAG_ERR_ARG, "too many partial lists for the merge");
-    hipLaunchKernelGGL(query_prepare_kernel, dim3(nq), dim3(256), 0, st, Q, d, max_row_norm, q16, eps);
+    hipLaunchKernelGGL(query_prepare_kernel, dim3(nq), dim3(256), 0, st, Q, d, max_row_norm, q16, eps, flags, w.n_flags);
     SDAG_HIP_CHECK(hipGetLastError());
     SDAG_HIP_CHECK(hipFuncSetAttribute((const void*)dense_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS));
     SDAG_HIP_CHECK(hipFuncSetAttribute((const void*)dense_scan<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS));
+    SDAG_HIP_CHECK(hipFuncSetAttribute((const void*)rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS));
     for (int q0 = 0; q0 < nq; q0 += QT) {
         const int nqt = nq - q0 < QT ? nq - q0 : QT;
         float* os = out_s + (int64_t)q0 * k;
         int64_t* oi = out_i + (int64_t)q0 * k;
-        SDAG_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), st));
+        int* flag = flags + q0 / QT;
         if (N > 0) {
             hipLaunchKernelGGL(dense_scan<true>, dim3(pl.n_wg), dim3(256), SCAN_LDS, st, (const void*)(q16 + (int64_t)q0 * d), nqt, C16,
-                               N, d, k, pl.rows_per_wg, part_s, part_i, (const int*)nullptr);
+                               N, d, ks, pl.rows_per_wg, part_s, part_i, (const int*)nullptr);
             SDAG_HIP_CHECK(hipGetLastError());
         }
-        hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, part_s, part_i, N > 0 ? pl.n_wg : 0, nqt, QT, k,
-                           (int64_t)0, approx_s, approx_i, (const int*)nullptr);
-        SDAG_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(rescore_kernel, dim3(nqt), dim3(256), 0, st, Q + (int64_t)q0 * d, C, d, k, part_s, part_i, N > 0 ? pl.n_wg : 0,
-                           approx_s, eps + q0, id_base, os, oi, flag);
+        hipLaunchKernelGGL(rescore_kernel, dim3(nqt), dim3(256), RS_LDS, st, Q + (int64_t)q0 * d, C, d, k, ks, part_s, part_i,
+                           N > 0 ? pl.n_wg : 0, eps + q0, id_base, os, oi, flag);
         SDAG_HIP_CHECK(hipGetLastError());
         if (N > 0) {
             // only when the rescoring kernel could not vouch for its candidate set: the exact scan of the batch

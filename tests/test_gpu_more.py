@@ -163,6 +163,34 @@ def test_dense_topk_full_corpus_properties():
     assert torch.equal(mi, i) and torch.equal(ms, s)
 
 
+@pytest.mark.parametrize("k", [1, 5, 10])
+def test_two_stage_search_on_clustered_unit_corpus(k):
+    """Unit-norm corpus of near-duplicate clusters that sit next to each other in row order (passages of one article),
+    queries close to a cluster: the whole top k comes from one stripe and its approximate scores are within the error
+    bound of each other.  Results must still be the oracle's bit for bit; whether the exact scan had to run is
+    printed (it must not for k = 1: a stripe keeps at least 8 entries, so a cluster of 6 near-duplicates of the best
+    row cannot look like an overflow)."""
+    import sdag_amd
+    from oracle import dense_ref
+
+    rng = np.random.default_rng(40 + k)
+    n_clusters, per, d = 8000, 6, 256
+    centers = rng.standard_normal((n_clusters, d), dtype=np.float32)
+    C = np.repeat(centers, per, axis=0) + 0.02 * rng.standard_normal((n_clusters * per, d), dtype=np.float32)
+    C /= np.linalg.norm(C, axis=1, keepdims=True)
+    Q = centers[rng.integers(0, n_clusters, 40)] + 0.05 * rng.standard_normal((40, d), dtype=np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    idx = sdag_amd.FlatIPIndex(d, device=DEV)
+    idx.add(C)
+    s, i = idx.search(Q, k)
+    gs, gi = dense_ref.dense_topk(Q, C, k)
+    assert np.array_equal(i, gi) and np.array_equal(s.view(np.uint32), gs.view(np.uint32))
+    fell = idx.last_search_fell_back()
+    print(f"clustered corpus k={k}: exact scan ran for the last batch: {fell}")
+    if k == 1:
+        assert not fell
+
+
 class FakeRanker:
     def __init__(self, d=64, device="cpu"):
         self.d, self.device = d, device
