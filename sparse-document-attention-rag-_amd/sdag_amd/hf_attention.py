@@ -9,6 +9,10 @@ block-sparse descriptor set for the duration of the prefill, and no dense mask e
 The single-token decode steps (SDAG.py:191-211: one new position against the whole cache, no mask from the
 reference) run the key/value-streaming kernel ``sdag_decode_attn``.  Any other call (an ordinary causal prefill, a
 padded batch) is handed to transformers' stock SDPA attention unchanged.
+
+Masks: the function is registered with transformers' mask interface under SDPA's mask builder, which hands the
+layers ``None`` whenever nothing but causality has to be enforced and decides that ONCE per forward pass; the layers
+here only test ``attention_mask is None`` and never read a mask tensor back (no device synchronisation per layer).
 """
 from __future__ import annotations
 
@@ -18,8 +22,8 @@ from typing import Optional
 
 import torch
 
-from .attention import decode_attention, sdag_attention
-from .descriptor import Descriptor
+from .attention import decode_attention, sdag_attention, sdag_attention_batch
+from .descriptor import BatchDescriptor, Descriptor
 
 ATTN_NAME = "sdag_hip"
 _state = threading.local()
@@ -30,8 +34,9 @@ def current_descriptor() -> Optional[Descriptor]:
 
 
 @contextlib.contextmanager
-def active_descriptor(desc: Descriptor):
-    """Make ``desc`` the mask of every prefill-shaped attention call on this thread inside the block."""
+def active_descriptor(desc):
+    """Make ``desc`` (a ``Descriptor``, or a ``BatchDescriptor`` for a right-padded batch of prompts) the mask of
+    every prefill-shaped attention call on this thread inside the block."""
     prev = getattr(_state, "desc", None)
     _state.desc = desc
     try:
@@ -41,21 +46,43 @@ def active_descriptor(desc: Descriptor):
 
 
 def _mask_allows_everything(attention_mask) -> bool:
-    """A decode step of an unpadded sequence: transformers passes no mask, or one that forbids nothing (looking
-    into a mask tensor costs a device synchronisation, which only padded batches pay)."""
-    if attention_mask is None:
-        return True
-    if attention_mask.dtype == torch.bool:
-        return bool(attention_mask.all())
-    return bool((attention_mask == 0).all())
+    """A decode step of an unpadded sequence gets no mask from transformers (see ``register``).  A mask tensor means
+    that something is forbidden (padding): such a step goes to SDPA with that mask; its contents are not inspected,
+    which would cost a device synchronisation per layer and step."""
+    return attention_mask is None
+
+
+def _dense_mask_fallback(module, query, key, value, desc, dropout, scaling, **kwargs):
+    """Prefill under a descriptor on a model the kernel does not cover (head_dim other than 128, query heads not a
+    multiple of key/value heads): SDPA under the dense mask expanded from the descriptor on the GPU."""
+    from transformers.integrations.sdpa_attention import sdpa_attention_forward
+
+    if not query.is_cuda:
+        raise RuntimeError("the SDAG attention path runs on the GPU only (no CPU fallback)")
+    dense = desc.materialize(query.device)
+    add = torch.zeros(dense.shape, dtype=query.dtype, device=query.device).masked_fill(~dense, torch.finfo(query.dtype).min)
+    return sdpa_attention_forward(module, query, key, value, add[None, None], dropout=dropout, scaling=scaling, **kwargs)
 
 
 def sdag_hip_attention_forward(module, query, key, value, attention_mask, dropout: float = 0.0,
                                scaling: Optional[float] = None, **kwargs):
     desc = current_descriptor()
+    if isinstance(desc, BatchDescriptor):
+        # several prompts in one forward pass, right-padded to a common length, each with its own descriptor
+        if query.shape[0] == desc.B and query.shape[2] == key.shape[2] >= desc.Lmax and query.shape[3] == 128:
+            if dropout:
+                raise NotImplementedError("attention dropout is not supported by the SDAG kernel (inference only)")
+            q, k, v = query, key, value
+            if q.dtype != torch.bfloat16:
+                q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+            out = sdag_attention_batch(q, k, v, desc, scaling=scaling, out_dtype=torch.bfloat16)
+            return (out if out.dtype == query.dtype else out.to(query.dtype)), None
+        desc = None
     if desc is not None and query.shape[2] == key.shape[2] == desc.L:
         if dropout:
             raise NotImplementedError("attention dropout is not supported by the SDAG kernel (inference only)")
+        if not (query.shape[3] == 128 and query.shape[1] % key.shape[1] == 0):  # (a CPU tensor: sdag_attention raises)
+            return _dense_mask_fallback(module, query, key, value, desc, dropout, scaling, **kwargs)
         q, k, v = query, key, value
         if q.dtype != torch.bfloat16:
             q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
@@ -80,6 +107,12 @@ def register() -> str:
     from transformers.modeling_utils import AttentionInterface
 
     AttentionInterface.register(ATTN_NAME, sdag_hip_attention_forward)
+    try:  # masks as for SDPA: None unless padding has to be enforced, decided once per forward pass
+        from transformers.masking_utils import AttentionMaskInterface, sdpa_mask
+
+        AttentionMaskInterface.register(ATTN_NAME, sdpa_mask)
+    except ImportError:  # a transformers without the mask interface: it builds no mask for unknown functions
+        pass
     return ATTN_NAME
 
 

@@ -5,4 +5,5 @@ from src.pipeline.sparse_attention_RAG.SDAG import (  # noqa: F401
     compute_doc_knn_for_docs,
     generate_with_custom_mask,
     run_rag_with_doc_isolation,
+    run_rag_with_doc_isolation_batch,
 )

@@ -262,3 +262,57 @@ def run_rag_with_doc_isolation(model, tokenizer, query: str, malicious_docs: Lis
     input_ids = tokenizer(chat_str, return_tensors="pt").to(device)["input_ids"]
     desc = sdag_amd.from_spans(input_ids.size(1), sys_user_len, spans, qa_start, neighbors)
     return _generate_with_descriptor(model, tokenizer, input_ids, desc, max_new_tokens=max_new_tokens)
+
+
+def _cache_of_sequence(past, b: int, length: int):
+    """The key/value cache of sequence ``b`` of a batched prefill, cut to its own ``length`` positions, as a cache
+    of its own (what a prefill of that prompt alone would have returned)."""
+    from transformers import DynamicCache
+
+    own = DynamicCache()
+    for layer_idx, layer in enumerate(past.layers):
+        own.update(layer.keys[b:b + 1, :, :length].contiguous(), layer.values[b:b + 1, :, :length].contiguous(), layer_idx)
+    return own
+
+
+def run_rag_with_doc_isolation_batch(model, tokenizer, queries: List[str], malicious_docs_batch: List[List[str]],
+                                     retrieved_docs_batch: List[list], max_new_tokens: int, device: str,
+                                     add_attack_in_rank, ranker, doc_neighbors_k: int) -> List[str]:
+    """``run_rag_with_doc_isolation`` for several queries at once (no counterpart in the reference, which answers one
+    query per call: src/pipeline/main.py:469-496).  The masked prefill -- where the time goes -- runs ONCE for all
+    prompts: they are right-padded to a common length, every prompt keeps its own descriptor, and each attention
+    layer is one batched kernel launch.  The answers are then decoded prompt by prompt from that prompt's slice of
+    the cache with the reference's loop, in order, so sampling draws from the global RNG in the same sequence as one
+    call per query would (the prefill draws nothing).  Returns one answer per query.
+    """
+    n = len(queries)
+    if not (n == len(malicious_docs_batch) == len(retrieved_docs_batch)):
+        raise ValueError("one list of malicious documents and one of retrieved documents per query expected")
+    if n == 0:
+        return []
+    ids, descs = [], []
+    for query, mal, docs in zip(queries, malicious_docs_batch, retrieved_docs_batch):
+        chat_str, sys_user_len, spans, qa_start, ranked_docs = build_rag_chat_and_spans(
+            tokenizer=tokenizer, system_prompt=SYSTEM_PROMPT_RAG, user_template=USER_RAG_PROMPT, query=query,
+            malicious_docs=mal, retrieved_docs=docs, add_attack_in_rank=add_attack_in_rank)
+        neighbors = None
+        if doc_neighbors_k and doc_neighbors_k > 0:
+            neighbors = compute_doc_knn_for_docs(ranker=ranker, docs=ranked_docs, k_neighbors=doc_neighbors_k)
+        input_ids = tokenizer(chat_str, return_tensors="pt").to(device)["input_ids"]
+        ids.append(input_ids)
+        descs.append(sdag_amd.from_spans(input_ids.size(1), sys_user_len, spans, qa_start, neighbors, max_items_per_unit=64))
+    lengths = [int(t.size(1)) for t in ids]
+    l_max = max(lengths)
+    pad_id = tokenizer.pad_token_id if getattr(tokenizer, "pad_token_id", None) is not None else (tokenizer.eos_token_id or 0)
+    batch_ids = torch.full((n, l_max), int(pad_id), dtype=ids[0].dtype, device=ids[0].device)
+    for b, t in enumerate(ids):
+        batch_ids[b, :lengths[b]] = t[0]
+    batch = sdag_amd.BatchDescriptor(descs)
+    answers: List[str] = []
+    with hf_attention.use_on_model(model):
+        with torch.no_grad(), hf_attention.active_descriptor(batch):
+            out = model(input_ids=batch_ids, use_cache=True)  # rows past a prompt's end attend nothing and are never read
+        for b in range(n):
+            first = type(out)(logits=out.logits[b:b + 1, :lengths[b]], past_key_values=_cache_of_sequence(out.past_key_values, b, lengths[b]))
+            answers.append(_decode_loop(model, tokenizer, ids[b], first, max_new_tokens))
+    return answers

@@ -198,6 +198,64 @@ def test_run_rag_with_doc_isolation_matches_reference_text(SDAG, monkeypatch):
         assert text == c["text"], c["name"]
 
 
+def test_batched_entry_point_matches_reference_texts(SDAG, monkeypatch):
+    """run_rag_with_doc_isolation_batch (one right-padded prefill for all prompts, per-prompt decoding): the same
+    texts the REFERENCE's per-query entry point produced, with the oracle standing in for the batched kernel."""
+    from helpers import FakeRanker, load_e2e, load_e2e_model
+    from sdag_amd import hf_attention
+    import sdag_amd
+
+    tok, g, path = load_e2e()
+    model, _ = load_e2e_model(g, path)
+    calls = {"batch": 0}
+
+    def oracle_batch(q, k, v, batch, scaling=None, out_dtype=torch.bfloat16):
+        calls["batch"] += 1
+        out = torch.zeros((q.shape[0], q.shape[2], q.shape[1], q.shape[3]), dtype=torch.float32)
+        for b, d in enumerate(batch.descs):
+            mask = torch.from_numpy(expand_descriptor(d.host))
+            out[b:b + 1, :d.L] = sdag_ref.masked_attention(q[b:b + 1, :, :d.L].float(), k[b:b + 1, :, :d.L].float(),
+                                                           v[b:b + 1, :, :d.L].float(), mask, scaling)
+        return out
+
+    def oracle_knn(emb, kept, n, k, device=None):
+        return sdag_ref.doc_knn_from_embeddings(emb.cpu().numpy(), kept, n, k)
+
+    monkeypatch.setattr(hf_attention, "sdag_attention_batch", oracle_batch)
+    monkeypatch.setattr(hf_attention.torch, "bfloat16", torch.float32, raising=False)
+    monkeypatch.setattr(sdag_amd, "doc_knn", oracle_knn)
+    monkeypatch.setattr(SDAG, "TEMPERATURE", 0)
+    # the batch call takes one attack rank and one neighbour count for all queries: group the fixture's cases by them
+    groups = {}
+    for c in g["e2e"]:
+        groups.setdefault((json.dumps(c["rank"]), c["nbr_k"]), []).append(c)
+    ranker = FakeRanker(g["ranker_dim"])
+    for (rank, nbr_k), cs in groups.items():
+        texts = SDAG.run_rag_with_doc_isolation_batch(model, tok, [c["query"] for c in cs], [c["mal"] for c in cs],
+                                                      [c["docs"] for c in cs], g["max_new_tokens"], "cpu", json.loads(rank),
+                                                      ranker, nbr_k)
+        assert texts == [c["text"] for c in cs]
+    # and a mixed batch: different prompts, one call (same rank and neighbour count passed for all)
+    cs = g["e2e"]
+    texts = SDAG.run_rag_with_doc_isolation_batch(model, tok, [c["query"] for c in cs], [c["mal"] for c in cs],
+                                                  [c["docs"] for c in cs], g["max_new_tokens"], "cpu", cs[0]["rank"], ranker, 0)
+    singles = [SDAG_single(SDAG, model, tok, c, g, cs[0]["rank"], ranker, monkeypatch) for c in cs]
+    assert texts == singles
+    assert calls["batch"] >= g["model_cfg"]["num_hidden_layers"]
+
+
+def SDAG_single(SDAG, model, tok, c, g, rank, ranker, monkeypatch):
+    """One query through the per-query entry point with the oracle standing in for the single-sequence kernel."""
+    from sdag_amd import hf_attention
+
+    def oracle_attention(q, k, v, desc, scaling=None, out_dtype=torch.bfloat16, out=None):
+        mask = torch.from_numpy(expand_descriptor(desc.host))
+        return sdag_ref.masked_attention(q.float(), k.float(), v.float(), mask, scaling)
+
+    monkeypatch.setattr(hf_attention, "sdag_attention", oracle_attention)
+    return SDAG.run_rag_with_doc_isolation(model, tok, c["query"], c["mal"], c["docs"], g["max_new_tokens"], "cpu", rank, ranker, 0)
+
+
 def test_ranked_list_injection_rules():
     from sdag_amd.ranked_list import inject_malicious_docs_into_ranked_list as inj
 

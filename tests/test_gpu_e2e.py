@@ -77,6 +77,50 @@ def test_run_rag_with_doc_isolation_end_to_end():
         SDAG.TEMPERATURE = old_t
 
 
+def test_batched_entry_point_on_gpu():
+    """run_rag_with_doc_isolation_batch: one right-padded prefill (one batched kernel launch per layer, a descriptor per
+    prompt) and per-prompt decoding.  Grouped by the fixture's (attack rank, neighbour count) its texts equal the
+    REFERENCE's; a mixed batch equals one call of the per-query entry point per prompt."""
+    import json
+
+    SDAG = importlib.import_module("src.pipeline.sparse_attention_RAG.SDAG")
+    from sdag_amd import hf_attention
+
+    tok, g, path = load_e2e()
+    model, _ = load_e2e_model(g, path, device=DEV)
+    old_t = SDAG.TEMPERATURE
+    SDAG.TEMPERATURE = 0
+    calls = {"batch": 0}
+    real = hf_attention.sdag_attention_batch
+
+    def counting(*a, **kw):
+        calls["batch"] += 1
+        return real(*a, **kw)
+
+    hf_attention.sdag_attention_batch = counting
+    try:
+        ranker = FakeRanker(g["ranker_dim"], device=DEV)
+        groups = {}
+        for c in g["e2e"]:
+            groups.setdefault((json.dumps(c["rank"]), c["nbr_k"]), []).append(c)
+        for (rank, nbr_k), cs in groups.items():
+            texts = SDAG.run_rag_with_doc_isolation_batch(model, tok, [c["query"] for c in cs], [c["mal"] for c in cs],
+                                                          [c["docs"] for c in cs], g["max_new_tokens"], DEV, json.loads(rank),
+                                                          ranker, nbr_k)
+            assert texts == [c["text"] for c in cs]
+        cs = g["e2e"]
+        calls["batch"] = 0
+        texts = SDAG.run_rag_with_doc_isolation_batch(model, tok, [c["query"] for c in cs], [c["mal"] for c in cs],
+                                                      [c["docs"] for c in cs], g["max_new_tokens"], DEV, 2, ranker, 1)
+        assert calls["batch"] == g["model_cfg"]["num_hidden_layers"]          # ONE launch per layer for all prompts
+        singles = [SDAG.run_rag_with_doc_isolation(model, tok, c["query"], c["mal"], c["docs"], g["max_new_tokens"], DEV, 2,
+                                                   ranker, 1) for c in cs]
+        assert texts == singles
+    finally:
+        hf_attention.sdag_attention_batch = real
+        SDAG.TEMPERATURE = old_t
+
+
 def test_mask_edited_in_place_is_honoured():
     """A mask from build_blocked_causal_mask_full that the caller edits in place afterwards: the prefill must follow
     the tensor's contents (SDAG.py:167-171), not the descriptor the tensor was expanded from."""

@@ -3,7 +3,7 @@
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts 128-byte fabric read requests as 64 bytes
 for wide (16 B per lane) coalesced reads, so the read side is doubled; WRITE_SIZE is taken as reported.
-usage: collect_traffic.py <fetch_csv> <write_csv> <out_json> [mode]
+usage: collect_traffic.py <fetch_csv> <write_csv> <out_json> [workload] [source tag]
 """
 import collections
 import csv
@@ -17,7 +17,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        m = re.search(r"(sdag_attn_main|sdag_attn_combine|dense_scan|topk_merge_kernel)", r["Kernel_Name"])
+        m = re.search(r"(sdag_attn_main|sdag_attn_combine|dense_scan|topk_merge_kernel|rescore_kernel)", r["Kernel_Name"])
         if not m:
             continue
         tot[m.group(1)] += float(r["Counter_Value"])
@@ -25,7 +25,7 @@ def per_kernel(path, counter):
     return {k: (tot[k] / n[k], n[k]) for k in tot}
 
 
-def main(fetch_csv, write_csv, out, mode="batched"):
+def main(fetch_csv, write_csv, out, mode="cfg3", source=""):
     f = per_kernel(fetch_csv, "FETCH_SIZE")
     w = per_kernel(write_csv, "WRITE_SIZE")
     res = {}
@@ -42,10 +42,12 @@ def main(fetch_csv, write_csv, out, mode="batched"):
     prev[mode] = res
     if "sdag_attn_main" in res:
         prev["sdag_attn_main_bytes_per_launch_" + mode] = res["sdag_attn_main"]["hbm_bytes_per_launch"]
+    if source:
+        prev["source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py on the builder's GPU lease ({source}); not measured in this run"
     res = prev
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])

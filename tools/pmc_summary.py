@@ -5,7 +5,7 @@ acc = collections.defaultdict(lambda: [0.0, 0])
 for d in sys.argv[1:]:
     for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(path)):
-            m = re.search(r"(sdag_attn_main|sdag_attn_combine|dense_scan|topk_merge_kernel)", r["Kernel_Name"])
+            m = re.search(r"(sdag_attn_main|sdag_attn_combine|dense_scan|topk_merge_kernel|rescore_kernel)", r["Kernel_Name"])
             if not m:
                 continue
             a = acc[(m.group(1), r["Counter_Name"])]
