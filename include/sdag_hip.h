@@ -170,6 +170,20 @@ int sdag_decode_attn(const void* q, const void* k, const void* v, void* o,
                      int B, int Hq, int Hkv, int S, int D, float scale,
                      void* workspace, int64_t workspace_bytes, int out_dtype, void* stream);
 
+/* The same step for several right-padded prompts decoded together (no call site in the reference, which decodes one
+ * query at a time, SDAG.py:191-211; used by the batched form of run_rag_with_doc_isolation): the cache of sequence b
+ * holds its prompt in rows [0, valid_len[b]), padding in rows [valid_len[b], pad_end) and the tokens generated so far
+ * in rows [pad_end, S); the padding rows take no part.  valid_len: B int32 on the device, 0 <= valid_len[b] <= pad_end
+ * <= S; a sequence must be left with at least one key. */
+int sdag_decode_attn_padded(const void* q, const void* k, const void* v, void* o,
+                            int64_t q_sb, int64_t q_sh,
+                            int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                            int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                            int64_t o_sb, int64_t o_sh,
+                            int B, int Hq, int Hkv, int S, int D, float scale,
+                            const int32_t* valid_len, int pad_end,
+                            void* workspace, int64_t workspace_bytes, int out_dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Exact inner-product search.  Replaces  scores, indices = index.search(q, top_k)
  * (src/pipeline/retrieval/dense.py:82-84; the arithmetic of the reference is inside faiss).

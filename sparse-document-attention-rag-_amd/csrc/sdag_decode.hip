@@ -41,6 +41,10 @@ struct DecodeParams {
     int out_f32;
     float c;       // scale * log2(e)
     float* part;   // [B][Hq][n_parts][PART_STRIDE]
+    // Right-padded prompts decoded together: keys [valid_len[b], pad_end) of sequence b are padding and take no part
+    // (valid_len == nullptr: every key below S counts).
+    const int32_t* valid_len;
+    int pad_end;
 };
 
 __device__ __forceinline__ float wave_max(float x) {
@@ -79,9 +83,11 @@ __global__ __launch_bounds__(64) void sdag_decode_main(const DecodeParams p) {
 
     const int g_begin = part * p.groups_per_part;
     const int g_end = min(g_begin + p.groups_per_part, (p.S + 63) / 64);
+    const int hole_lo = p.valid_len ? p.valid_len[b] : p.S, hole_hi = p.valid_len ? p.pad_end : p.S;  // wave-uniform
     for (int g = g_begin; g < g_end; ++g) {
+        if (g * 64 >= hole_lo && g * 64 + 64 <= hole_hi) continue;  // 64 keys of padding
         const int key = g * 64 + lane;
-        const bool live = key < p.S;
+        const bool live = key < p.S && !(key >= hole_lo && key < hole_hi);
         // ---- all loads of the group first: this lane's K row (16 x 16 bytes) and, coalesced, one 4-byte column pair
         // of each of the 64 V rows, so that the V rows travel while the scores are computed (rows past the end of
         // the sequence are clamped to the last key; their probability is 0)
@@ -217,12 +223,13 @@ extern "C" int64_t sdag_decode_workspace_bytes(int B, int Hq, int S) {
     return (((int64_t)B * Hq * n_parts * PART_STRIDE * (int64_t)sizeof(float)) + 255) & ~255ll;
 }
 
-extern "C" int sdag_decode_attn(const void* q, const void* k, const void* v, void* o,
+namespace {
+int decode_launch(const void* q, const void* k, const void* v, void* o,
                                 int64_t q_sb, int64_t q_sh,
                                 int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                 int64_t v_sb, int64_t v_sh, int64_t v_sl,
                                 int64_t o_sb, int64_t o_sh,
-                                int B, int Hq, int Hkv, int S, int Dh, float scale,
+                                int B, int Hq, int Hkv, int S, int Dh, float scale, const int32_t* valid_len, int pad_end,
                                 void* workspace, int64_t workspace_bytes_, int out_dtype, void* stream) {
     if (Dh != D) return fail(SDAG_ERR_ARG, "head_dim %d not supported (only 128)", Dh);
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || S <= 0 || Hq % Hkv) return fail(SDAG_ERR_ARG, "bad B/Hq/Hkv/S");
@@ -244,6 +251,8 @@ extern "C" int sdag_decode_attn(const void* q, const void* k, const void* v, voi
     p.out_f32 = out_dtype == SDAG_OUT_F32;
     p.c = scale * 1.4426950408889634f;
     p.part = (float*)workspace;
+    p.valid_len = valid_len;
+    p.pad_end = pad_end;
     const int64_t blocks = (int64_t)B * Hkv * p.HG * p.n_parts;
     if (blocks > 0x7fffffff) return fail(SDAG_ERR_ARG, "grid too large");
     hipLaunchKernelGGL(sdag_decode_main, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, p);
@@ -251,4 +260,30 @@ extern "C" int sdag_decode_attn(const void* q, const void* k, const void* v, voi
     hipLaunchKernelGGL(sdag_decode_merge, dim3((unsigned)(B * Hq)), dim3(256), 0, (hipStream_t)stream, p);
     SDAG_HIP_CHECK(hipGetLastError());
     return SDAG_OK;
+}
+}  // namespace
+
+extern "C" int sdag_decode_attn(const void* q, const void* k, const void* v, void* o,
+                                int64_t q_sb, int64_t q_sh,
+                                int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                                int64_t o_sb, int64_t o_sh,
+                                int B, int Hq, int Hkv, int S, int Dh, float scale,
+                                void* workspace, int64_t workspace_bytes_, int out_dtype, void* stream) {
+    return decode_launch(q, k, v, o, q_sb, q_sh, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sh, B, Hq, Hkv, S, Dh, scale, nullptr, 0,
+                         workspace, workspace_bytes_, out_dtype, stream);
+}
+
+extern "C" int sdag_decode_attn_padded(const void* q, const void* k, const void* v, void* o,
+                                       int64_t q_sb, int64_t q_sh,
+                                       int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                       int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                                       int64_t o_sb, int64_t o_sh,
+                                       int B, int Hq, int Hkv, int S, int Dh, float scale,
+                                       const int32_t* valid_len, int pad_end,
+                                       void* workspace, int64_t workspace_bytes_, int out_dtype, void* stream) {
+    if (!valid_len) return fail(SDAG_ERR_ARG, "valid_len is NULL");
+    if (pad_end < 0 || pad_end > S) return fail(SDAG_ERR_ARG, "pad_end outside [0, S]");
+    return decode_launch(q, k, v, o, q_sb, q_sh, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sh, B, Hq, Hkv, S, Dh, scale, valid_len,
+                         pad_end, workspace, workspace_bytes_, out_dtype, stream);
 }

@@ -17,6 +17,25 @@ from .descriptor import BatchDescriptor, Descriptor
 _workspaces: Dict[torch.device, torch.Tensor] = {}
 
 
+class _on_device:
+    """``torch.cuda.device(dev)`` only when ``dev`` is not already current (the context manager costs more than the
+    kernel launch it would wrap in a single-token step)."""
+
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev: torch.device):
+        self.ctx = None if dev.index is None or torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
+
+
 def _workspace(device: torch.device, nbytes: int) -> Optional[torch.Tensor]:
     if nbytes == 0:
         return None
@@ -65,7 +84,7 @@ def sdag_attention(
     ws_bytes = desc.workspace_bytes(B, Hq, Hkv)
     ws = _workspace(dev, ws_bytes)
     ddev = desc.device(dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = _lib.lib().sdag_attn_fwd(
             query.data_ptr(), key.data_ptr(), value.data_ptr(), out.data_ptr(),
             query.stride(0), query.stride(1), query.stride(2),
@@ -167,12 +186,14 @@ def sdag_attention_batch(query, key, value, batch: BatchDescriptor, scaling: Opt
     return out
 
 
-def decode_attention(query, key, value, scaling: Optional[float] = None, out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+def decode_attention(query, key, value, scaling: Optional[float] = None, out_dtype: torch.dtype = torch.bfloat16,
+                     valid_len: Optional[torch.Tensor] = None, pad_end: int = 0) -> torch.Tensor:
     """Attention of ONE new token per sequence over the whole key/value cache (no mask): the attention of the
     reference's decode steps (src/pipeline/sparse_attention_RAG/SDAG.py:191-199).
 
     query [B, Hq, 1, D], key / value [B, Hkv, S, D] bf16 (any batch / head / row strides, D contiguous); returns
-    [B, 1, Hq, D]."""
+    [B, 1, Hq, D].  ``valid_len`` (int32 [B] on the device) with ``pad_end``: right-padded prompts decoded together --
+    cache rows [valid_len[b], pad_end) of sequence b are padding and take no part."""
     if not (query.is_cuda and key.is_cuda and value.is_cuda):
         raise RuntimeError("decode_attention runs on the GPU only (no CPU fallback)")
     if query.dtype != torch.bfloat16 or key.dtype != torch.bfloat16 or value.dtype != torch.bfloat16:
@@ -193,15 +214,19 @@ def decode_attention(query, key, value, scaling: Optional[float] = None, out_dty
     out = torch.empty((B, 1, Hq, D), dtype=out_dtype, device=dev)
     lib = _lib.lib()
     ws = _workspace(dev, int(lib.sdag_decode_workspace_bytes(B, Hq, S)))
-    with torch.cuda.device(dev):
-        rc = lib.sdag_decode_attn(
-            query.data_ptr(), key.data_ptr(), value.data_ptr(), out.data_ptr(),
+    head = (query.data_ptr(), key.data_ptr(), value.data_ptr(), out.data_ptr(),
             query.stride(0), query.stride(1),
             key.stride(0), key.stride(1), key.stride(2),
             value.stride(0), value.stride(1), value.stride(2),
             out.stride(0), out.stride(2),
-            B, Hq, Hkv, S, D, float(D ** -0.5 if scaling is None else scaling),
-            ws.data_ptr(), ws.numel(), _lib.OUT_F32 if out_dtype == torch.float32 else _lib.OUT_BF16,
-            _lib.stream_ptr(dev))
+            B, Hq, Hkv, S, D, float(D ** -0.5 if scaling is None else scaling))
+    tail = (ws.data_ptr(), ws.numel(), _lib.OUT_F32 if out_dtype == torch.float32 else _lib.OUT_BF16, _lib.stream_ptr(dev))
+    with _on_device(dev):
+        if valid_len is None:
+            rc = lib.sdag_decode_attn(*head, *tail)
+        else:
+            if valid_len.dtype != torch.int32 or valid_len.device != dev or valid_len.numel() != B or not valid_len.is_contiguous():
+                raise ValueError("valid_len must be a contiguous int32 [B] tensor on the tensors' device")
+            rc = lib.sdag_decode_attn_padded(*head, valid_len.data_ptr(), int(pad_end), *tail)
     _lib.check(rc)
     return out

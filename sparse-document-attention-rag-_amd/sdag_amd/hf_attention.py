@@ -45,6 +45,23 @@ def active_descriptor(desc):
         _state.desc = prev
 
 
+@contextlib.contextmanager
+def active_padding(valid_len: torch.Tensor, pad_end: int):
+    """Single-token steps of right-padded prompts decoded together: cache rows [valid_len[b], pad_end) of sequence b
+    are padding (``valid_len``: int32 [B] on the model's device) and are left out of every decode-shaped attention
+    call on this thread inside the block."""
+    prev = getattr(_state, "padding", None)
+    _state.padding = (valid_len, int(pad_end))
+    try:
+        yield
+    finally:
+        _state.padding = prev
+
+
+def _on_gpu(t: torch.Tensor) -> bool:
+    return t.is_cuda
+
+
 def _mask_allows_everything(attention_mask) -> bool:
     """A decode step of an unpadded sequence gets no mask from transformers (see ``register``).  A mask tensor means
     that something is forbidden (padding): such a step goes to SDPA with that mask; its contents are not inspected,
@@ -90,13 +107,19 @@ def sdag_hip_attention_forward(module, query, key, value, attention_mask, dropou
         if out.dtype != query.dtype:
             out = out.to(query.dtype)
         return out, None
-    if (query.shape[2] == 1 and key.shape[2] >= 1 and not dropout and query.is_cuda and query.shape[3] == 128
+    padding = getattr(_state, "padding", None)
+    if (query.shape[2] == 1 and key.shape[2] >= 1 and not dropout and _on_gpu(query) and query.shape[3] == 128
             and query.shape[1] % key.shape[1] == 0 and _mask_allows_everything(attention_mask)):
         q, k, v = query, key, value
         if q.dtype != torch.bfloat16:
             q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
-        out = decode_attention(q, k, v, scaling=scaling, out_dtype=torch.bfloat16)
+        if padding is not None and padding[0].numel() == query.shape[0]:
+            out = decode_attention(q, k, v, scaling=scaling, out_dtype=torch.bfloat16, valid_len=padding[0], pad_end=padding[1])
+        else:
+            out = decode_attention(q, k, v, scaling=scaling, out_dtype=torch.bfloat16)
         return (out if out.dtype == query.dtype else out.to(query.dtype)), None
+    if padding is not None and query.shape[2] == 1:
+        raise RuntimeError("batched decoding of padded prompts needs the GPU decode kernel (head_dim 128, no dropout, no mask)")
     from transformers.integrations.sdpa_attention import sdpa_attention_forward
 
     return sdpa_attention_forward(module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)

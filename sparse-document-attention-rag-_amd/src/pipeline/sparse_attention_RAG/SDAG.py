@@ -275,16 +275,62 @@ def _cache_of_sequence(past, b: int, length: int):
     return own
 
 
+def _decode_loop_batched(model, tokenizer, ids: List[torch.Tensor], out, lengths: List[int], max_new_tokens: int) -> List[str]:
+    """The reference's decode loop (SDAG.py:178-213) for all prompts of a right-padded prefill at once: one model
+    call per step for the whole batch.  Per prompt the rules are the reference's: up to max_new_tokens + 1 tokens, the
+    end-of-sequence token ends that prompt's answer (later steps of a finished prompt are computed and discarded);
+    the loop stops when every prompt has finished.  New tokens sit behind the padding in the cache (rows l_max + t of
+    every sequence) and carry their own positions lengths[b] + t; the padding rows are left out by the decode kernel.
+    """
+    n, l_max = len(ids), max(lengths)
+    dev = out.logits.device
+    valid = torch.tensor(lengths, dtype=torch.int32, device=dev)
+    last = torch.tensor([l - 1 for l in lengths], device=dev)
+    past = out.past_key_values
+    tok = _sample(out.logits[torch.arange(n, device=dev), last])                      # [n, 1]
+    new_tokens = [tok]
+    finished = torch.zeros(n, dtype=torch.bool, device=dev)
+    pos = valid.to(torch.long).unsqueeze(1)                                             # position of the token fed next
+    with hf_attention.active_padding(valid, l_max):
+        for _ in range(max_new_tokens):
+            with torch.no_grad():
+                step = model(input_ids=tok, past_key_values=past, position_ids=pos, use_cache=True)
+            past = step.past_key_values
+            tok = _sample(step.logits[:, -1, :])
+            new_tokens.append(tok)
+            pos = pos + 1
+            # the reference tests for EOS after appending the token (SDAG.py:208-211); a finished prompt stays finished
+            finished = finished | (tok[:, 0] == tokenizer.eos_token_id)
+            if bool(finished.all()):
+                break
+    gen = torch.cat(new_tokens, dim=1).cpu()
+    answers = []
+    for b in range(n):
+        row = gen[b]
+        # keep the tokens up to and including the first EOS among those produced inside the loop (the first token,
+        # sampled from the prefill, is never tested, as in the reference)
+        hits = (row[1:] == tokenizer.eos_token_id).nonzero()
+        end = int(hits[0]) + 2 if len(hits) else len(row)
+        answers.append(tokenizer.decode(row[:end], skip_special_tokens=True).strip())
+    return answers
+
+
 def run_rag_with_doc_isolation_batch(model, tokenizer, queries: List[str], malicious_docs_batch: List[List[str]],
                                      retrieved_docs_batch: List[list], max_new_tokens: int, device: str,
-                                     add_attack_in_rank, ranker, doc_neighbors_k: int) -> List[str]:
+                                     add_attack_in_rank, ranker, doc_neighbors_k: int,
+                                     decode: str = "per_prompt") -> List[str]:
     """``run_rag_with_doc_isolation`` for several queries at once (no counterpart in the reference, which answers one
     query per call: src/pipeline/main.py:469-496).  The masked prefill -- where the time goes -- runs ONCE for all
     prompts: they are right-padded to a common length, every prompt keeps its own descriptor, and each attention
     layer is one batched kernel launch.  The answers are then decoded prompt by prompt from that prompt's slice of
     the cache with the reference's loop, in order, so sampling draws from the global RNG in the same sequence as one
-    call per query would (the prefill draws nothing).  Returns one answer per query.
+    call per query would (the prefill draws nothing).  ``decode="batched"`` decodes all prompts together instead (one
+    model call per step for the whole batch: the weights stream once per step rather than once per prompt and step);
+    greedy answers are the same, sampled ones come from the same distributions but draw from the RNG in another order.
+    Returns one answer per query.
     """
+    if decode not in ("per_prompt", "batched"):
+        raise ValueError("decode must be 'per_prompt' or 'batched'")
     n = len(queries)
     if not (n == len(malicious_docs_batch) == len(retrieved_docs_batch)):
         raise ValueError("one list of malicious documents and one of retrieved documents per query expected")
@@ -303,7 +349,9 @@ def run_rag_with_doc_isolation_batch(model, tokenizer, queries: List[str], malic
         descs.append(sdag_amd.from_spans(input_ids.size(1), sys_user_len, spans, qa_start, neighbors, max_items_per_unit=64))
     lengths = [int(t.size(1)) for t in ids]
     l_max = max(lengths)
-    pad_id = tokenizer.pad_token_id if getattr(tokenizer, "pad_token_id", None) is not None else (tokenizer.eos_token_id or 0)
+    pad_id = getattr(tokenizer, "pad_token_id", None)  # any valid id: rows past a prompt's end are never read
+    if pad_id is None or pad_id < 0:
+        pad_id = max(0, tokenizer.eos_token_id or 0)
     batch_ids = torch.full((n, l_max), int(pad_id), dtype=ids[0].dtype, device=ids[0].device)
     for b, t in enumerate(ids):
         batch_ids[b, :lengths[b]] = t[0]
@@ -312,6 +360,8 @@ def run_rag_with_doc_isolation_batch(model, tokenizer, queries: List[str], malic
     with hf_attention.use_on_model(model):
         with torch.no_grad(), hf_attention.active_descriptor(batch):
             out = model(input_ids=batch_ids, use_cache=True)  # rows past a prompt's end attend nothing and are never read
+        if decode == "batched":
+            return _decode_loop_batched(model, tokenizer, ids, out, lengths, max_new_tokens)
         for b in range(n):
             first = type(out)(logits=out.logits[b:b + 1, :lengths[b]], past_key_values=_cache_of_sequence(out.past_key_values, b, lengths[b]))
             answers.append(_decode_loop(model, tokenizer, ids[b], first, max_new_tokens))

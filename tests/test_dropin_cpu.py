@@ -243,6 +243,65 @@ def test_batched_entry_point_matches_reference_texts(SDAG, monkeypatch):
     assert texts == singles
     assert calls["batch"] >= g["model_cfg"]["num_hidden_layers"]
 
+    # decode="batched": one model call per step for all prompts; the padding rows of the cache are left out by the
+    # decode kernel (here: its fp32 restatement), every prompt keeps its own positions and its own end
+    def oracle_decode(q, k, v, scaling=None, out_dtype=torch.bfloat16, valid_len=None, pad_end=0):
+        B, Hq, _, D = q.shape
+        G = Hq // k.shape[1]
+        out = torch.empty((B, 1, Hq, D), dtype=torch.float32)
+        for b in range(B):
+            keep = torch.ones(k.shape[2], dtype=torch.bool)
+            if valid_len is not None:
+                keep[int(valid_len[b]):pad_end] = False
+            kk = k[b].float().repeat_interleave(G, dim=0)[:, keep]
+            vv = v[b].float().repeat_interleave(G, dim=0)[:, keep]
+            w = torch.softmax(q[b].float() @ kk.transpose(1, 2) * scaling, dim=-1)
+            out[b, 0] = (w @ vv)[:, 0]
+        return out
+
+    decode_calls = {"padded": 0}
+
+    def counting_decode(*a, **kw):
+        decode_calls["padded"] += kw.get("valid_len") is not None
+        return oracle_decode(*a, **kw)
+
+    monkeypatch.setattr(hf_attention, "decode_attention", counting_decode)
+    monkeypatch.setattr(hf_attention, "_on_gpu", lambda t: True)
+    texts = SDAG.run_rag_with_doc_isolation_batch(model, tok, [c["query"] for c in cs], [c["mal"] for c in cs],
+                                                  [c["docs"] for c in cs], g["max_new_tokens"], "cpu", cs[0]["rank"], ranker, 0,
+                                                  decode="batched")
+    assert texts == singles and decode_calls["padded"] > 0
+
+    # prompts that end early: with the end-of-sequence id set to a token that some answers contain, both decode modes
+    # must cut exactly those answers at it (and a first token equal to it ends nothing, as in the reference)
+    class TokProxy:
+        def __init__(self, inner, eos):
+            self.inner, self.eos_token_id, self.seen = inner, eos, []
+
+        def __getattr__(self, name):
+            return getattr(self.inner, name)
+
+        def __call__(self, *a, **kw):
+            return self.inner(*a, **kw)
+
+        def decode(self, ids_, **kw):
+            self.seen.append([int(x) for x in ids_])
+            return self.inner.decode(ids_, **kw)
+
+    probe = TokProxy(tok, -1)
+    args = ([c["query"] for c in cs], [c["mal"] for c in cs], [c["docs"] for c in cs], g["max_new_tokens"], "cpu", cs[0]["rank"], ranker, 0)
+    SDAG.run_rag_with_doc_isolation_batch(model, probe, *args, decode="batched")
+    full = probe.seen
+    assert all(len(x) == g["max_new_tokens"] + 1 for x in full)
+    for eos in {full[0][2], full[1][0], full[2][g["max_new_tokens"]], full[3][1]}:
+        pa, pb = TokProxy(tok, eos), TokProxy(tok, eos)
+        ta = SDAG.run_rag_with_doc_isolation_batch(model, pa, *args, decode="per_prompt")
+        tb = SDAG.run_rag_with_doc_isolation_batch(model, pb, *args, decode="batched")
+        assert ta == tb and pa.seen == pb.seen
+        for ids_, whole in zip(pa.seen, full):
+            cut = next((i for i in range(1, len(whole)) if whole[i] == eos), len(whole) - 1)
+            assert ids_ == whole[:cut + 1]
+
 
 def SDAG_single(SDAG, model, tok, c, g, rank, ranker, monkeypatch):
     """One query through the per-query entry point with the oracle standing in for the single-sequence kernel."""

@@ -116,6 +116,11 @@ def test_batched_entry_point_on_gpu():
         singles = [SDAG.run_rag_with_doc_isolation(model, tok, c["query"], c["mal"], c["docs"], g["max_new_tokens"], DEV, 2,
                                                    ranker, 1) for c in cs]
         assert texts == singles
+        # all prompts decoded together (padded decode kernel, per-prompt positions): the same greedy answers
+        together = SDAG.run_rag_with_doc_isolation_batch(model, tok, [c["query"] for c in cs], [c["mal"] for c in cs],
+                                                         [c["docs"] for c in cs], g["max_new_tokens"], DEV, 2, ranker, 1,
+                                                         decode="batched")
+        assert together == singles
     finally:
         hf_attention.sdag_attention_batch = real
         SDAG.TEMPERATURE = old_t

@@ -499,3 +499,37 @@ def test_decode_attention_matches_fp32_softmax(B, Hq, Hkv, S):
     assert _rel_err(o, ref) <= 1e-3
     ob = sdag_amd.decode_attention(q.to(DEV), k.to(DEV), v.to(DEV), scaling=scale).cpu()
     assert torch.equal(ob, o.to(torch.bfloat16))
+
+
+def test_decode_attention_with_padded_prompts():
+    """Right-padded prompts decoded together: cache rows [valid_len[b], pad_end) of sequence b take no part.  Against
+    the fp32 softmax over the remaining keys, 1e-3 of max |ref| per head; bf16 output = rounding of the fp32 output;
+    valid_len == pad_end for every sequence gives the bits of the plain call."""
+    import sdag_amd
+
+    B, Hq, Hkv, pad_end, S = 5, 32, 8, 333, 340
+    valid = [333, 1, 64, 200, 129]
+    g = torch.Generator().manual_seed(77)
+    q = torch.randn(B, Hq, 1, 128, generator=g).to(torch.bfloat16)
+    k = torch.randn(B, S, Hkv, 128, generator=g).to(torch.bfloat16).transpose(1, 2)
+    v = (torch.randn(B, Hkv, S, 128, generator=g) * 2).to(torch.bfloat16)
+    for b in range(B):                                   # garbage in the padding must not leak: make it loud
+        k[b, :, valid[b]:pad_end] = 50.0
+        v[b, :, valid[b]:pad_end] = 1000.0
+    G = Hq // Hkv
+    ref = torch.empty(B, 1, Hq, 128)
+    for b in range(B):
+        keep = torch.ones(S, dtype=torch.bool)
+        keep[valid[b]:pad_end] = False
+        kk = k[b].float().repeat_interleave(G, dim=0)[:, keep]
+        vv = v[b].float().repeat_interleave(G, dim=0)[:, keep]
+        ref[b, 0] = (torch.softmax(q[b].float() @ kk.transpose(1, 2) * 0.09, dim=-1) @ vv)[:, 0]
+    vl = torch.tensor(valid, dtype=torch.int32, device=DEV)
+    o = sdag_amd.decode_attention(q.to(DEV), k.to(DEV), v.to(DEV), scaling=0.09, out_dtype=torch.float32, valid_len=vl, pad_end=pad_end).cpu()
+    assert torch.isfinite(o).all() and _rel_err(o, ref) <= 1e-3
+    ob = sdag_amd.decode_attention(q.to(DEV), k.to(DEV), v.to(DEV), scaling=0.09, valid_len=vl, pad_end=pad_end).cpu()
+    assert torch.equal(ob, o.to(torch.bfloat16))
+    full = torch.full((B,), pad_end, dtype=torch.int32, device=DEV)
+    a = sdag_amd.decode_attention(q.to(DEV), k.to(DEV), v.to(DEV), scaling=0.09, out_dtype=torch.float32, valid_len=full, pad_end=pad_end)
+    c = sdag_amd.decode_attention(q.to(DEV), k.to(DEV), v.to(DEV), scaling=0.09, out_dtype=torch.float32)
+    assert torch.equal(a, c)
