@@ -94,6 +94,25 @@ with torch.no_grad():
                 return model(input_ids=bids, use_cache=True).logits[:, -1]
         t, _ = sync_time(ours_b, reps=2)
         res["prefill_ms_per_prompt_sdag_kernel_batch8"] = t * 1e3 / B
+        # the 8 prompts decoded together: one model call per step for the batch (padded decode kernel)
+        with hf_attention.active_descriptor(batch):
+            outb = model(input_ids=bids, use_cache=True)
+        valid = torch.full((B,), L, dtype=torch.int32, device=dev)
+        def decode_batch(o):
+            past, tok, pos = o.past_key_values, o.logits[:, -1:].argmax(-1), valid.long().unsqueeze(1)
+            with hf_attention.active_padding(valid, L):
+                for _ in range(n_dec):
+                    st = model(input_ids=tok, past_key_values=past, position_ids=pos, use_cache=True)
+                    past, tok, pos = st.past_key_values, st.logits[:, -1:].argmax(-1), pos + 1
+            return tok
+        decode_batch(outb); torch.cuda.synchronize()
+        with hf_attention.active_descriptor(batch):
+            outb = model(input_ids=bids, use_cache=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); decode_batch(outb); torch.cuda.synchronize()
+        res["decode_ms_per_step_batch8_sdag_kernel"] = (time.perf_counter() - t0) / n_dec * 1e3
+        res["decode_tokens_per_s_batch8_sdag_kernel"] = B * n_dec / (time.perf_counter() - t0)
+        del outb
     addb = add.expand(B, 1, L, L)
     t, _ = sync_time(lambda: model(input_ids=bids, attention_mask=addb, use_cache=True).logits[:, -1], reps=2)
     res["prefill_ms_per_prompt_dense_mask_sdpa_batch8"] = t * 1e3 / B
