@@ -179,6 +179,70 @@ def test_attention_benchmark_head_layout():
     assert d2.n_uniform_rows == 10
 
 
+def test_pipeline_chain_sharded_hybrid_selection_generation():
+    """The flow of the end-to-end configuration at small scale, through the modules that carry the reference's names:
+    corpus sharded over the ranks of an RCCL group (one rank here) -> DenseRetriever -> HybridRetriever (a lexical
+    stand-in for the JVM retriever) -> Near / Far selection for the batch -> batched generation.  Every stage against
+    its own check: search against the oracle, selection against per-query calls, answers against per-query calls."""
+    import torch.distributed as dist
+
+    import sdag_amd
+    from oracle import dense_ref
+    dense = importlib.import_module("src.pipeline.retrieval.dense")
+    hybrid = importlib.import_module("src.pipeline.retrieval.hybrid")
+    sel = importlib.import_module("src.pipeline.attack.malicious_selection")
+    SDAG = importlib.import_module("src.pipeline.sparse_attention_RAG.SDAG")
+    from sdag_amd.datamodels import RetrievalBatch
+
+    tok, g, path = load_e2e()
+    model, _ = load_e2e_model(g, path, device=DEV)
+    rk = FakeRanker(g["ranker_dim"], device=DEV)
+    _, sentence = __import__("helpers").make_bpe_tokenizer(seed=3)
+    passages = [sentence(8, 30) for _ in range(400)]
+    emb = rk.encode(["passage: " + t for t in passages]).float()
+    meta = [{"id": 5000 + i, "text": t} for i, t in enumerate(passages)]
+    queries = [sentence(3, 7) + "?" for _ in range(3)]
+
+    class Lexical(hybrid.Retriever):                       # shares words with the query: enough for a second ranking
+        def retrieve_batch(self, qs, k, bs):
+            out_t, out_i, out_s = [], [], []
+            for q in qs:
+                words = set(q.lower().split())
+                sc = sorted(((len(words & set(t.lower().split())), -i) for i, t in enumerate(passages)), reverse=True)[:k]
+                out_t.append([passages[-j] for _, j in sc])
+                out_i.append([str(5000 - j) for _, j in sc])
+                out_s.append([float(n) for n, _ in sc])
+            return RetrievalBatch(q_embs=[None] * len(qs), docs_texts_full=out_t, ids_full=out_i, scores_full=out_s)
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29654")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    old_t = SDAG.TEMPERATURE
+    SDAG.TEMPERATURE = 0
+    try:
+        index = sdag_amd.ShardedFlatIPIndex(g["ranker_dim"], len(passages), DEV)
+        index.add_local(emb)
+        dr = dense.DenseRetriever(rk, index, meta)
+        rb = dr.retrieve_batch(queries, 6, 2)
+        qe = rk.encode(["query: " + q for q in queries]).float().cpu().numpy()
+        rs, ri = dense_ref.dense_topk(qe, emb.cpu().numpy(), 6)
+        assert rb.ids_full == [[str(5000 + int(j)) for j in row] for row in ri]
+        fused = hybrid.HybridRetriever(dr, Lexical(), seed=11).retrieve_batch(queries, 5, 2)
+        assert all(len(x) == 5 for x in fused.docs_texts_full)
+        cands = [[sentence(4, 10) for _ in range(4)] for _ in queries]
+        chosen = sel.select_malicious_docs_for_batch(rk, fused.docs_texts_full, cands, "closest_to_centroid", 1)
+        assert chosen == [sel._select_malicious_docs_for_query(rk, d_, c_, "closest_to_centroid", 1)
+                          for d_, c_ in zip(fused.docs_texts_full, cands)]
+        answers = SDAG.run_rag_with_doc_isolation_batch(model, tok, queries, chosen, fused.docs_texts_full, 4, DEV, 2, rk, 2,
+                                                        decode="batched")
+        singles = [SDAG.run_rag_with_doc_isolation(model, tok, q, m_, d_, 4, DEV, 2, rk, 2)
+                   for q, m_, d_ in zip(queries, chosen, fused.docs_texts_full)]
+        assert answers == singles and all(isinstance(a, str) for a in answers)
+    finally:
+        SDAG.TEMPERATURE = old_t
+        dist.destroy_process_group()
+
+
 def _unit_corpus(n, d, seed):
     g = torch.Generator(device=DEV).manual_seed(seed)
     out = torch.empty((n, d), dtype=torch.float32, device=DEV)
