@@ -533,3 +533,64 @@ def test_decode_attention_with_padded_prompts():
     a = sdag_amd.decode_attention(q.to(DEV), k.to(DEV), v.to(DEV), scaling=0.09, out_dtype=torch.float32, valid_len=full, pad_end=pad_end)
     c = sdag_amd.decode_attention(q.to(DEV), k.to(DEV), v.to(DEV), scaling=0.09, out_dtype=torch.float32)
     assert torch.equal(a, c)
+
+
+def test_random_layout_sweep_masks_and_attention():
+    """Forty more random prompts (0-8 documents of 0-120 tokens, gaps 0-3, neighbours with out-of-range and repeated
+    ids, overlapping spans, wrong-length neighbour lists): the expanded descriptor equals the oracle's mask bit for bit
+    and the attention output is within 1e-3 of the oracle's, for random head layouts and unit lengths."""
+    import sdag_amd
+    from oracle import sdag_ref
+
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for case in range(40):
+        n_docs = int(rng.integers(0, 9))
+        lens = [int(x) for x in rng.integers(0, 121, n_docs)]
+        sys_len = int(rng.integers(0, 90))
+        spans, qa, L = synthetic_layout(sys_len, lens, int(rng.integers(0, 4)), int(rng.integers(0, 40)))
+        L = max(L, 1)
+        spans = [list(sp) for sp in spans]
+        if case % 4 == 1 and n_docs >= 2:
+            spans[1][0] = max(0, spans[1][0] - int(rng.integers(1, 20)))          # overlap with the document before
+        nbr = None
+        if case % 3:
+            nbr = [[int(x) for x in rng.integers(-2, n_docs + 2, int(rng.integers(0, 4)))] for _ in range(n_docs)]
+            if case % 7 == 0 and nbr:
+                nbr = nbr[:-1]                                                    # wrong length: ignored wholesale
+        qa_eff = min(qa, L)
+        mask = sdag_ref.mask_from_spans(L, min(sys_len, L), spans, qa_eff, nbr)
+        T, ns = [0, 1, 2, 5][case % 4], [0, 1, 7, 64][(case // 4) % 4]
+        d = sdag_amd.from_spans(L, min(sys_len, L), spans, qa_eff, nbr, max_items_per_unit=T, n_streams=ns)
+        assert np.array_equal(d.materialize(DEV).cpu().numpy(), mask), case
+        Hq, Hkv = [(4, 1), (8, 2), (2, 2), (12, 4), (5, 1)][case % 5]
+        g = torch.Generator().manual_seed(case)
+        q = torch.randn(1, L, Hq, 128, generator=g).to(torch.bfloat16).transpose(1, 2)
+        k = torch.randn(1, L, Hkv, 128, generator=g).to(torch.bfloat16).transpose(1, 2)
+        v = torch.randn(1, Hkv, L, 128, generator=g).to(torch.bfloat16)
+        ref = sdag_ref.masked_attention(q, k, v, torch.from_numpy(mask), 128 ** -0.5)
+        o = sdag_amd.sdag_attention(q.to(DEV), k.to(DEV), v.to(DEV), d, out_dtype=torch.float32).cpu()
+        assert torch.isfinite(o).all(), case
+        err = _rel_err(o, ref)
+        worst = max(worst, err)
+        assert err <= 1e-3, (case, err)
+    print("random sweep: worst rel err", worst)
+
+
+def test_attention_long_causal_prompt():
+    """A plain causal prompt of 16,384 tokens (no documents: the reference's mask is then the causal triangle), one
+    head: 256 key tiles per row block, split units, against the oracle."""
+    import sdag_amd
+    from oracle import sdag_ref
+
+    L = 16384
+    g = torch.Generator().manual_seed(16)
+    q = torch.randn(1, 1, L, 128, generator=g).to(torch.bfloat16)
+    k = torch.randn(1, 1, L, 128, generator=g).to(torch.bfloat16)
+    v = torch.randn(1, 1, L, 128, generator=g).to(torch.bfloat16)
+    d = sdag_amd.from_spans(L, L, [], L, None)
+    assert d.allowed_pairs == L * (L + 1) // 2
+    o = sdag_amd.sdag_attention(q.to(DEV), k.to(DEV), v.to(DEV), d, out_dtype=torch.float32).cpu()
+    mask = torch.ones(L, L, dtype=torch.bool).tril_()
+    ref = sdag_ref.masked_attention(q, k, v, mask, 128 ** -0.5)
+    assert _rel_err(o, ref) <= 1e-3
