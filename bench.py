@@ -42,6 +42,7 @@ sys.path.insert(0, os.path.join(ROOT, "sparse-document-attention-rag-_amd"))
 sys.path.insert(0, ROOT)
 
 RESULT_OUT = sys.stdout
+T_START = time.perf_counter()
 HBM_PEAK = 8.0e12      # B/s, MI355X HBM3E spec
 BF16_PEAK = 2.5e15     # FLOP/s dense
 
@@ -125,6 +126,12 @@ def prompts_of(cfg):
         nbr = [[(d + j) % K for j in range(1, cfg["nbr"] + 1)] for d in range(K)] if cfg["nbr"] else None
         out.append((spans, pos, pos + cfg["qa_len"], nbr))
     return out
+
+
+def trace(msg):
+    """Progress lines on stderr when BENCH_TRACE=1 (to see where a multi-rank run stands)."""
+    if os.environ.get("BENCH_TRACE") == "1":
+        print(f"[bench rank {os.environ.get('RANK', '0')} +{time.perf_counter() - T_START:.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def make_corpus(n, d, device, seed=0):
@@ -312,6 +319,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    trace("process group ready")
     import sdag_amd
     from sdag_amd import _lib
 
@@ -348,6 +356,7 @@ def main():
         index = local_index = sdag_amd.FlatIPIndex.from_tensor(make_corpus(cfg["corpus_n"], cfg["dim"], dev, seed=0),
                                                               two_stage=not args.exact_scan)
     local_index.prepare()   # index construction (the bf16 copy of the two-stage search), not part of a search
+    trace("corpus resident")
     # cfg5: every rank holds the embeddings of all queries of the step (same seed everywhere) and answers its own 32
     gq = torch.Generator(device=dev).manual_seed(77 if cfg["sharded"] else 77 + rank)
     Q = torch.randn((nq_search, cfg["dim"]), generator=gq, device=dev, dtype=torch.float32)
@@ -382,6 +391,7 @@ def main():
         e0, e1, e2 = ev(), ev(), ev()
         e0.record()
         index.search_device(Q, k)
+        trace("search enqueued")
         if cfg["centroid"]:
             _lib.check(lib.sdag_centroid_sims_batch(cen_R.data_ptr(), cen_off.data_ptr(), cen_C.data_ptr(), cen_off[nb + 1:].data_ptr(),
                                                     nb, cfg["dim"], cen_out.data_ptr(), cen_sims.data_ptr(), stream))
@@ -413,13 +423,16 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+        trace("warmup step enqueued")
     sync()
+    trace("warmup done")
     pipe.host_s, pipe.builds, enqueue_s[0] = 0.0, 0, 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     sync()
     elapsed = time.perf_counter() - t0
+    trace("timed steps done")
     if dist is not None and world > 1:
         t = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

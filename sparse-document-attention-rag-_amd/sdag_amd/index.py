@@ -214,6 +214,12 @@ def gather_partials(mine: torch.Tensor, group=None) -> torch.Tensor:
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
+    if mine.is_cuda and dist.get_backend(group) == "gloo":
+        # a CPU-only backend (rehearsals on one GPU): stage through the host explicitly
+        host = mine.contiguous().cpu()
+        flat = torch.empty((world * host.shape[0],) + tuple(host.shape[1:]), dtype=host.dtype)
+        dist.all_gather_into_tensor(flat, host, group=group)
+        return flat.view((world,) + tuple(mine.shape)).to(mine.device)
     flat = torch.empty((world * mine.shape[0],) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
     dist.all_gather_into_tensor(flat, mine.contiguous(), group=group)
     return flat.view((world,) + tuple(mine.shape))
