@@ -91,7 +91,7 @@ int sdag_mask_materialize(const int32_t* desc_host, const int32_t* desc_dev, uin
  * pointers 16-byte aligned).  o: [B, L, Hq, D] with element strides o_sb / o_sl / o_sh, bf16 or fp32
  * (out_dtype).  The same descriptor applies to every batch element.  Hq must be a multiple of Hkv.
  * Limits (SDAG_ERR_ARG beyond them): every stride below 2^31 elements; the L rows of one (batch, head)
- * slice of k and of v span less than 4 GiB (L * k_sl * 2 bytes), those of o less than 2 GiB.
+ * slice of q, of k and of v span less than 4 GiB (L * k_sl * 2 bytes), those of o less than 2 GiB.
  * workspace: device scratch of at least sdag_attn_workspace_bytes() bytes (may be NULL when that is 0).
  */
 int64_t sdag_attn_workspace_bytes(const int32_t* desc_host, int B, int Hq, int Hkv);

@@ -232,11 +232,15 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
 
     // ---- Q fragments: B operand of S^T = K Q^T; lane (r, h) holds Q[row][16 ks + 8 h .. +7].
     bf16x8 qf[8];
+    // Buffer loads: one descriptor per unit over this head's slice of sequence b (wave-uniform), a 32-bit offset per
+    // lane (its row, its half of every 32-byte piece) and the piece as the instruction's immediate.
     auto load_q = [&](int b, int row0, int L) {
-        const int row_ld = min(row0 + r, L - 1);
-        const unsigned short* qp = p.q + (int64_t)b * p.q_sb + (int64_t)hq * p.q_sh + (int64_t)row_ld * p.q_sl + 8 * h;
+        const unsigned qrow = (unsigned)p.q_sl * 2u;
+        const auto qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.q + (int64_t)b * p.q_sb + (int64_t)hq * p.q_sh), 0,
+                                                           (int)((unsigned)(L - 1) * qrow + (unsigned)(D * 2)), 0x00020000);
+        const unsigned qoff = (unsigned)min(row0 + r, L - 1) * qrow + 16u * (unsigned)h;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(qrs, qoff + 32u * ks, 0, 0));
     };
 
     // ---- staging geometry: thread covers chunk (tid & 15) of rows (tid >> 4) + 16 i, i = 0..3.
@@ -611,8 +615,8 @@ int check_common(const Tensors& t, int B, int Hq, int Hkv, int L, int Dh, float 
     const int64_t strides[] = {t.q_sb, t.q_sh, t.q_sl, t.k_sb, t.k_sh, t.k_sl, t.v_sb, t.v_sh, t.v_sl, t.o_sb, t.o_sl, t.o_sh};
     for (int64_t st : strides)
         if (st < 0 || (st & 7) || st > 0x7fffffff) return fail(SDAG_ERR_ARG, "strides must be non-negative multiples of 8 elements below 2^31");
-    if ((int64_t)L * t.k_sl * 2 >= (1ll << 32) || (int64_t)L * t.v_sl * 2 >= (1ll << 32))
-        return fail(SDAG_ERR_ARG, "one (batch, head) slice of K or V must span less than 4 GiB");
+    if ((int64_t)L * t.q_sl * 2 >= (1ll << 32) || (int64_t)L * t.k_sl * 2 >= (1ll << 32) || (int64_t)L * t.v_sl * 2 >= (1ll << 32))
+        return fail(SDAG_ERR_ARG, "one (batch, head) slice of Q, K or V must span less than 4 GiB");
     if ((int64_t)L * t.o_sl * 2 >= (1ll << 31)) return fail(SDAG_ERR_ARG, "one (batch, head) slice of O must span less than 2 GiB");
     if (((uintptr_t)t.q | (uintptr_t)t.k | (uintptr_t)t.v | (uintptr_t)t.o) & 15) return fail(SDAG_ERR_ARG, "tensor pointers must be 16-byte aligned");
     return SDAG_OK;
