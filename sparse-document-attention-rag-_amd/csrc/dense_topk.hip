@@ -41,14 +41,20 @@ constexpr int QT = 32;                      // queries per pass
 constexpr int TR = 128;                     // corpus rows per tile
 constexpr int KC = 32;                      // fp32 dimensions per stage (128 bytes of a row)
 constexpr int KC16 = 64;                    // bf16 dimensions per stage (the same 128 bytes)
-constexpr int NST = 3;                      // LDS ring depth
+#ifndef SDAG_SCAN_NST
+#define SDAG_SCAN_NST 3
+#define SDAG_SCAN_WG_PER_CU 2
+#endif
+constexpr int NST = SDAG_SCAN_NST;          // LDS ring depth: loads run NST - 1 stages ahead of the MFMAs
+constexpr int SCAN_WAIT = 5 * (NST - 2);    // vector-memory operations of the stages after the current one (5 per stage and wave)
 constexpr int C_STAGE = TR * KC * 4;        // 16 KiB
 constexpr int Q_STAGE = QT * KC * 4;        // 4 KiB
 constexpr int STAGE_BYTES = C_STAGE + Q_STAGE;
 constexpr int CAP = 64;                     // candidate list capacity per query
 constexpr int PUSH_MAX = 32;                // most entries one filter round can append to one list
 constexpr int MAX_K = 32;
-constexpr int MAX_WG = 512;
+constexpr int MAX_WG = 512;                 // stripe lists the merge and rescoring kernels can take
+constexpr int SCAN_WG = 256 * SDAG_SCAN_WG_PER_CU;  // workgroups of the scan: what the chip holds at once
 constexpr int OFF_CS = NST * STAGE_BYTES;           // float cand_s[QT][CAP]
 constexpr int OFF_CI = OFF_CS + QT * CAP * 4;       // int   cand_i[QT][CAP]
 constexpr int OFF_CNT = OFF_CI + QT * CAP * 4;      // int   cnt[QT]
@@ -102,7 +108,7 @@ __device__ __forceinline__ void compact_list(unsigned char* smem, int j, int k, 
 // (64 dimensions per 128-byte stage, one v_mfma_f32_32x32x16_bf16 per 16 dimensions): approximate scores, used only
 // to pick candidates for exact rescoring.  run_flag (optional): the kernel does nothing when *run_flag == 0.
 template <bool BF16>
-__global__ __launch_bounds__(256, 2) void dense_scan(const void* __restrict__ Qv, int nq, const void* __restrict__ Cv,
+__global__ __launch_bounds__(256, SDAG_SCAN_WG_PER_CU) void dense_scan(const void* __restrict__ Qv, int nq, const void* __restrict__ Cv,
                                                      int64_t N, int d, int k, int rows_per_wg,
                                                      float* __restrict__ part_s, int* __restrict__ part_i,
                                                      const int* __restrict__ run_flag) {
@@ -164,13 +170,13 @@ __global__ __launch_bounds__(256, 2) void dense_scan(const void* __restrict__ Qv
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-    issue(0);
-    issue(1);
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0) issue(s0);
     int tile = 0, kc = 0;
     for (int s = 0; s < S; ++s) {
-        // stage s landed for this wave (5 newer DMA pieces may still fly), then for every wave
-        asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
-        issue(s + 2);
+        // stage s landed for this wave (the pieces of the newer stages may still fly), then for every wave
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(SCAN_WAIT) : "memory");
+        issue(s + NST - 1);
         const unsigned char* sb = smem + (s % NST) * STAGE_BYTES;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -350,11 +356,9 @@ __global__ __launch_bounds__(MRG_THREADS) void topk_merge_kernel(const float* __
 // k-th best exact score is at least that, and a row that reaches it exactly is within eps of it approximately.
 // The candidate scan keeps the best ks approximate scores per stripe (ks = scan_keep(k) >= k: a margin, so that a
 // stripe holding several of the best rows does not look as if it had dropped one); the rescoring kernel takes every
-// entry >= LB - 2 eps with LB <= a_k (see there), scores it with the exact fp32 chain and ranks.  A stripe whose ks
-// entries are all candidates, or more candidates than fit, raise a flag, and the exact scan then runs for the batch
-// (the flag is read on the device: no host round trip).
-constexpr int RS_CMAX = 512;  // candidates per query the rescoring kernel holds
-constexpr int RS_DC = 128;    // dimensions per LDS chunk
+// entry >= LB - 2 eps with LB <= a_k (see there), scores it with the exact fp32 chain and ranks (RS_G blocks per query,
+// their lists merged by the merge kernel).  A stripe whose ks entries are all candidates, or more candidates than fit,
+// raise a flag, and the exact scan then runs for the batch (the flag is read on the device: no host round trip).
 
 __host__ __device__ inline float eps_rel(int d) { return 0.0079f + (float)d * 1.2e-7f; }
 
@@ -422,121 +426,182 @@ __global__ __launch_bounds__(256) void corpus_prepare_kernel(const float* __rest
     }
 }
 
-// One block per query: find the candidates in the stripe lists, rescore them with the exact chain, write the best k.
+// Rescoring: find the candidates in the stripe lists, score them with the exact chain, keep the best k.
 //
 // The stripe lists hold the best ks >= k approximate scores of every stripe, sorted best first.  Threshold: the k-th
 // largest of the stripes' maxima is a lower bound LB of a_k (they are scores of k distinct rows), so every row of the
 // exact top k has an approximate score >= LB - 2 eps; every list entry above that line is a candidate (a superset of
 // the set a_k itself would give: no separate merge of the lists is needed to know a_k).  A stripe whose ks entries are
-// ALL candidates may have dropped one, and more than RS_CMAX candidates do not fit: either raises the flag that makes
-// the exact scan run for the batch.
-constexpr int RS_G2 = 128;    // candidates rescored per pass
-constexpr int RS_LDS = RS_G2 * (RS_DC + 1) * 4;  // dynamic LDS of the rescoring kernel: the row chunk image
+// ALL candidates may have dropped one, and more than RS_CB candidates among one block's stripes do not fit: either
+// raises the flag that makes the exact scan run for the batch.
+constexpr int RS_G = 16;      // blocks per query: block g takes the stripes p with p % RS_G == g
+constexpr int RS_CB = 32;     // candidates one block holds (and scores together)
+constexpr int RS_DC = 256;    // dimensions of every candidate row in LDS at a time
+constexpr int RS_RW = RS_DC + 4;  // row stride of the LDS image in floats: 16 threads reading 16 bytes each hit 64 banks
 
+// Order-preserving map of a float's bits to an unsigned integer (larger float = larger key; -inf lowest of all values
+// that occur here), and back.
+__device__ __forceinline__ unsigned float_key(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(unsigned key) {
+    return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+}
+
+// The k-th largest of the 512 keys a wave holds (8 per lane), ties counted with multiplicity: the key is built from the
+// top bit down, keeping a bit whenever at least k keys reach the value it would give.  Wave-uniform, no LDS.
+__device__ __forceinline__ unsigned wave_kth_largest(const unsigned (&key)[8], int k) {
+    unsigned prefix = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned trial = prefix | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[i] >= trial));
+        if (cnt >= k) prefix = trial;
+    }
+    return prefix;
+}
+
+// grid (RS_G, queries).  Every block finds the line (all stripes' maxima: 2 KB of loads), collects the candidates of
+// ITS stripes, scores them with the exact chain and writes its best k, sorted, as one partial list per (block, query)
+// in the layout the merge kernel reads; the merge of the RS_G lists gives the result.
 __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ Q, const float* __restrict__ C, int d, int k, int ks,
                                                       const float* __restrict__ part_s, const int* __restrict__ part_i, int n_wg,
-                                                      const float* __restrict__ eps, int64_t id_base, float* __restrict__ out_s,
-                                                      int64_t* __restrict__ out_i, int* __restrict__ flag) {
-    extern __shared__ __attribute__((aligned(16))) float rows[];  // [RS_G2][RS_DC + 1]
-    __shared__ int cand[RS_CMAX];
-    __shared__ float ex[RS_CMAX];
-    __shared__ float mx[MAX_WG];
-    __shared__ float qs[RS_DC];
-    __shared__ float lb_s;
-    __shared__ int n_s, bad_s;
-    const int q = blockIdx.x, tid = threadIdx.x;
-    if (tid == 0) { n_s = 0; bad_s = 0; lb_s = -INFINITY; }
-    // ---- the stripes' maxima, and LB = the k-th largest of them (by counting, ties by stripe index)
-    for (int p = tid; p < MAX_WG; p += 256) {
-        float v = -INFINITY;
-        if (p < n_wg) {
-            const int64_t src = ((int64_t)p * QT + q) * ks;
-            if (part_i[src] >= 0) v = part_s[src];
+                                                      const float* __restrict__ eps, float* __restrict__ blk_s, int* __restrict__ blk_i,
+                                                      int* __restrict__ flag) {
+    __shared__ __attribute__((aligned(16))) float rows[RS_CB * RS_RW];
+    __shared__ __attribute__((aligned(16))) float qs[RS_DC];
+    __shared__ int cand[RS_CB];
+    __shared__ float ex[RS_CB];
+    __shared__ int qual[MAX_WG / RS_G];
+    __shared__ int n_s, nqual_s, bad_s;
+    const int g = blockIdx.x, q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) { n_s = 0; nqual_s = 0; bad_s = 0; }
+    // ---- the stripes' maxima (stripe 64 i + lane in key[i]; every wave holds all of them), and LB = the k-th largest
+    // (-inf when fewer than k stripes hold a row: then everything is a candidate)
+    unsigned key[MAX_WG / 64];
+#pragma unroll
+    for (int i = 0; i < MAX_WG / 64; ++i) {
+        const int p = 64 * i + lane;
+        const int64_t src = ((int64_t)(p < n_wg ? p : 0) * QT + q) * ks;
+        const int id0 = part_i[src];   // both words requested together: one round trip
+        const float s0 = part_s[src];
+        key[i] = float_key(p < n_wg && id0 >= 0 ? s0 : -INFINITY);
+    }
+    const float lb = key_float(wave_kth_largest(key, k));
+    const float thr = lb == -INFINITY ? -INFINITY : lb - 2.0f * eps[q];
+    const unsigned thr_key = float_key(thr);
+    __syncthreads();  // the counters are zero
+    // ---- candidates: this block's stripes whose maximum reaches the line, then every (stripe, place) pair of those at
+    // once (the lists are sorted, so the entries above the line are a prefix of each)
+    if (w == 0 && (lane % RS_G) == g % RS_G) {
+#pragma unroll
+        for (int i = 0; i < MAX_WG / 64; ++i) {
+            const int p = 64 * i + lane;
+            if (p % RS_G == g && p < n_wg && key[i] >= thr_key) qual[atomicAdd(&nqual_s, 1)] = p;
         }
-        mx[p] = v;
     }
     __syncthreads();
-    for (int p = tid; p < MAX_WG; p += 256) {
-        const float v = mx[p];
-        int rank = 0;
-        for (int j2 = 0; j2 < MAX_WG; ++j2) rank += (mx[j2] > v || (mx[j2] == v && j2 < p)) ? 1 : 0;
-        if (rank == k - 1) lb_s = v;  // -inf when fewer than k stripes hold a row: then everything is a candidate
-    }
-    __syncthreads();
-    const float thr = lb_s == -INFINITY ? -INFINITY : lb_s - 2.0f * eps[q];
-    // ---- candidates: only stripes whose maximum reaches the line are walked (their lists are sorted)
-    for (int p = tid; p < n_wg; p += 256) {
-        if (!(mx[p] >= thr)) continue;
-        const int64_t src = ((int64_t)p * QT + q) * ks;
-        int t = 0;
-        for (; t < ks; ++t) {
-            const int id = part_i[src + t];
-            if (id < 0 || !(part_s[src + t] >= thr)) break;
-            const int pos = atomicAdd(&n_s, 1);
-            if (pos < RS_CMAX) cand[pos] = id;
-        }
-        if (t == ks) bad_s = 1;  // the stripe's list is full of candidates: it may have dropped one
+    const int npairs = nqual_s * ks;
+    for (int e = tid; e < npairs; e += 256) {
+        const int p = qual[e / ks], t = e - (e / ks) * ks;
+        const int64_t src = ((int64_t)p * QT + q) * ks + t;
+        const int id = part_i[src];
+        const float sc = part_s[src];
+        if (id < 0 || !(sc >= thr)) continue;
+        const int pos = atomicAdd(&n_s, 1);
+        if (pos < RS_CB) cand[pos] = id;
+        if (t == ks - 1) bad_s = 1;  // the stripe's list is full of candidates: it may have dropped one
     }
     __syncthreads();
     int n = n_s;
-    if (n > RS_CMAX) {
-        n = RS_CMAX;
+    if (n > RS_CB) {
+        n = RS_CB;
         if (tid == 0) bad_s = 1;
     }
-    // ---- exact scores: thread t < RS_G2 owns candidate g0 + t.  Rows and the query pass through LDS in chunks of
-    // RS_DC dimensions; the next chunk's pieces are already in flight (in registers) while a chunk is consumed.
-    // Dimensions past d are staged as zeros: fma(0, 0, acc) leaves the chain's value unchanged.
-    constexpr int PIECES = RS_G2 * (RS_DC / 4) / 256;  // float4 pieces per thread and chunk
-    constexpr int RW = RS_DC + 1;
-    for (int g0 = 0; g0 < n; g0 += RS_G2) {
-        float acc = 0.f;
-        f32x4 pre[PIECES];
-        float preq = 0.f;
-        auto fetch = [&](int dc) {
+    // ---- exact scores: thread t < n walks candidate t's chain; the rows pass through LDS RS_DC dimensions at a time,
+    // the next piece of every row already requested (in registers) while the chains consume the current one.  (A large
+    // row image would be no faster: workgroups that take most of a compute unit's LDS start tens of microseconds apart.)
+    constexpr int PER_ROW = RS_DC / 4, PIECES = RS_CB * PER_ROW / 256;
+    f32x4 pre[PIECES], preq;
+    auto fetch = [&](int dc) {
 #pragma unroll
-            for (int i2 = 0; i2 < PIECES; ++i2) {
-                const int e = tid + 256 * i2;
-                const int rr = e / (RS_DC / 4), c4 = e - rr * (RS_DC / 4);
-                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                pre[i2] = (g0 + rr < n && dc + 4 * c4 < d) ? *reinterpret_cast<const f32x4*>(C + (int64_t)cand[g0 + rr] * d + dc + 4 * c4) : zero;
-            }
-            if (tid < RS_DC) preq = dc + tid < d ? Q[(int64_t)q * d + dc + tid] : 0.f;
-        };
-        fetch(0);
-        for (int dc = 0; dc < d; dc += RS_DC) {
-            __syncthreads();  // the previous chunk has been consumed
+        for (int i = 0; i < PIECES; ++i) {
+            const int e = tid + 256 * i, rr = e / PER_ROW, c4 = e % PER_ROW;
+            if (rr < n && dc + 4 * c4 < d) pre[i] = *reinterpret_cast<const f32x4*>(C + (int64_t)cand[rr] * d + dc + 4 * c4);
+        }
+        if (tid < PER_ROW && dc + 4 * tid < d) preq = *reinterpret_cast<const f32x4*>(Q + (int64_t)q * d + dc + 4 * tid);
+    };
+    float acc = 0.f;
+    if (n > 0) fetch(0);
+    for (int dc = 0; n > 0 && dc < d; dc += RS_DC) {
+        const int dn = d - dc < RS_DC ? d - dc : RS_DC;  // a multiple of 64
+        __syncthreads();  // the previous piece has been consumed
 #pragma unroll
-            for (int i2 = 0; i2 < PIECES; ++i2) {
-                const int e = tid + 256 * i2;
-                const int rr = e / (RS_DC / 4), c4 = e - rr * (RS_DC / 4);
-                float* rp = rows + rr * RW + 4 * c4;
-                rp[0] = pre[i2][0]; rp[1] = pre[i2][1]; rp[2] = pre[i2][2]; rp[3] = pre[i2][3];
+        for (int i = 0; i < PIECES; ++i) {
+            const int e = tid + 256 * i, rr = e / PER_ROW, c4 = e % PER_ROW;
+            if (rr < n && dc + 4 * c4 < d) *reinterpret_cast<f32x4*>(rows + rr * RS_RW + 4 * c4) = pre[i];
+        }
+        if (tid < PER_ROW && dc + 4 * tid < d) *reinterpret_cast<f32x4*>(qs + 4 * tid) = preq;
+        __syncthreads();
+        if (dc + RS_DC < d) fetch(dc + RS_DC);
+        if (tid < n) {
+            // 32 dimensions of the row and of the query in registers while the 32 before them go through the chain
+            const float* rp = rows + tid * RS_RW;
+            f32x4 ca[8], qa[8], cb[8], qb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ca[u] = *reinterpret_cast<const f32x4*>(rp + 4 * u);
+                qa[u] = *reinterpret_cast<const f32x4*>(qs + 4 * u);
             }
-            if (tid < RS_DC) qs[tid] = preq;
-            __syncthreads();
-            if (dc + RS_DC < d) fetch(dc + RS_DC);
-            if (tid < RS_G2 && g0 + tid < n) {
-                const float* rp = rows + tid * RW;
-#pragma unroll 32
-                for (int j2 = 0; j2 < RS_DC; ++j2) acc = __builtin_fmaf(rp[j2], qs[j2], acc);
+            for (int j = 0; j < dn; j += 64) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    cb[u] = *reinterpret_cast<const f32x4*>(rp + j + 32 + 4 * u);
+                    qb[u] = *reinterpret_cast<const f32x4*>(qs + j + 32 + 4 * u);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc = __builtin_fmaf(ca[u][0], qa[u][0], acc);
+                    acc = __builtin_fmaf(ca[u][1], qa[u][1], acc);
+                    acc = __builtin_fmaf(ca[u][2], qa[u][2], acc);
+                    acc = __builtin_fmaf(ca[u][3], qa[u][3], acc);
+                }
+                if (j + 64 < dn) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        ca[u] = *reinterpret_cast<const f32x4*>(rp + j + 64 + 4 * u);
+                        qa[u] = *reinterpret_cast<const f32x4*>(qs + j + 64 + 4 * u);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc = __builtin_fmaf(cb[u][0], qb[u][0], acc);
+                    acc = __builtin_fmaf(cb[u][1], qb[u][1], acc);
+                    acc = __builtin_fmaf(cb[u][2], qb[u][2], acc);
+                    acc = __builtin_fmaf(cb[u][3], qb[u][3], acc);
+                }
             }
         }
-        if (tid < RS_G2 && g0 + tid < n) ex[g0 + tid] = acc;
     }
+    if (tid < n) ex[tid] = acc;
     __syncthreads();
+    // ---- this block's best k, sorted, as partial list g of query q
+    const int64_t ob = ((int64_t)g * QT + q) * k;
     for (int c = tid; c < n; c += 256) {
         const float sc = ex[c];
         const int ic = cand[c];
         int rank = 0;
         for (int j2 = 0; j2 < n; ++j2) rank += better(ex[j2], cand[j2], sc, ic) ? 1 : 0;
-        if (rank < k && sc == sc) {
-            out_s[(int64_t)q * k + rank] = sc;
-            out_i[(int64_t)q * k + rank] = (int64_t)ic + id_base;
+        if (rank < k) {
+            blk_s[ob + rank] = sc;
+            blk_i[ob + rank] = sc == sc ? ic : -1;
         }
     }
     if (tid < k && tid >= n) {
-        out_s[(int64_t)q * k + tid] = -FLT_MAX;
-        out_i[(int64_t)q * k + tid] = -1;
+        blk_s[ob + tid] = -FLT_MAX;
+        blk_i[ob + tid] = -1;
     }
     if (tid == 0 && bad_s) atomicOr(flag, 1);
 }
@@ -594,7 +659,7 @@ __global__ __launch_bounds__(256) void centroid_batch_kernel(const float* __rest
 struct ScanPlan { int n_wg; int rows_per_wg; };
 inline ScanPlan plan_scan(int64_t N) {
     int64_t tiles = (N + TR - 1) / TR;
-    int64_t n_wg = tiles < MAX_WG ? tiles : MAX_WG;
+    int64_t n_wg = tiles < SCAN_WG ? tiles : SCAN_WG;
     if (n_wg < 1) n_wg = 1;
     int64_t tiles_per = (tiles + n_wg - 1) / n_wg;
     if (tiles_per < 1) tiles_per = 1;
@@ -663,7 +728,7 @@ extern "C" int sdag_corpus_to_bf16(const float* C, int64_t N, int d, void* C16, 
 }
 
 namespace {
-struct Ws2 { int64_t part_s, part_i, flag, eps, q16, exact, total; int n_flags; };
+struct Ws2 { int64_t part_s, part_i, flag, eps, q16, exact, rs, total; int n_flags; };
 Ws2 plan_ws2(int nq, int64_t N, int d, int k) {
     const ScanPlan pl = plan_scan(N);
     const int ks = scan_keep(k);
@@ -677,6 +742,7 @@ Ws2 plan_ws2(int nq, int64_t N, int d, int k) {
     w.eps = take((int64_t)nq * 4);
     w.q16 = take((int64_t)nq * d * 2);
     w.exact = take((int64_t)pl.n_wg * QT * k * 8);
+    w.rs = take((int64_t)RS_G * QT * k * 8);  // the rescoring blocks' partial lists
     w.total = off;
     return w;
 }
@@ -715,13 +781,14 @@ extern "C" int sdag_dense_topk2(const float* Q, int nq, const float* C, const vo
     unsigned short* q16 = (unsigned short*)(ws + w.q16);
     float* ex_s = (float*)(ws + w.exact);
     int* ex_i = (int*)(ex_s + (int64_t)pl.n_wg * QT * k);
+    float* rs_s = (float*)(ws + w.rs);
+    int* rs_i = (int*)(rs_s + (int64_t)RS_G * QT * k);
     const int ks = scan_keep(k);
     if ((((int64_t)pl.n_wg * k + 63) / 64) * k > MRG_A) return fail(SDAG_ERR_ARG, "too many partial lists for the merge");
     hipLaunchKernelGGL(query_prepare_kernel, dim3(nq), dim3(256), 0, st, Q, d, max_row_norm, q16, eps, flags, w.n_flags);
     SDAG_HIP_CHECK(hipGetLastError());
     SDAG_HIP_CHECK(hipFuncSetAttribute((const void*)dense_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS));
     SDAG_HIP_CHECK(hipFuncSetAttribute((const void*)dense_scan<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS));
-    SDAG_HIP_CHECK(hipFuncSetAttribute((const void*)rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS));
     for (int q0 = 0; q0 < nq; q0 += QT) {
         const int nqt = nq - q0 < QT ? nq - q0 : QT;
         float* os = out_s + (int64_t)q0 * k;
@@ -732,8 +799,11 @@ extern "C" int sdag_dense_topk2(const float* Q, int nq, const float* C, const vo
                                N, d, ks, pl.rows_per_wg, part_s, part_i, (const int*)nullptr);
             SDAG_HIP_CHECK(hipGetLastError());
         }
-        hipLaunchKernelGGL(rescore_kernel, dim3(nqt), dim3(256), RS_LDS, st, Q + (int64_t)q0 * d, C, d, k, ks, part_s, part_i,
-                           N > 0 ? pl.n_wg : 0, eps + q0, id_base, os, oi, flag);
+        hipLaunchKernelGGL(rescore_kernel, dim3(RS_G, nqt), dim3(256), 0, st, Q + (int64_t)q0 * d, C, d, k, ks, part_s, part_i,
+                           N > 0 ? pl.n_wg : 0, eps + q0, rs_s, rs_i, flag);
+        SDAG_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, rs_s, rs_i, RS_G, nqt, QT, k, id_base, os, oi,
+                           (const int*)nullptr);
         SDAG_HIP_CHECK(hipGetLastError());
         if (N > 0) {
             // only when the rescoring kernel could not vouch for its candidate set: the exact scan of the batch
