@@ -184,6 +184,20 @@ int sdag_decode_attn_padded(const void* q, const void* k, const void* v, void* o
                             const int32_t* valid_len, int pad_end,
                             void* workspace, int64_t workspace_bytes, int out_dtype, void* stream);
 
+/* The same step over a PREALLOCATED cache of S rows of which only the first *n_rows hold keys (no call site in the
+ * reference, whose cache grows by concatenation, SDAG.py:191-199; for decode steps captured once as a HIP graph and
+ * replayed: the launch arguments stay the same from step to step, the number of cached rows is read on the device).
+ * n_rows: one int32 on the device, 1 <= *n_rows <= S at the time the kernel runs (the same for every sequence).
+ * valid_len / pad_end as for sdag_decode_attn_padded, or valid_len NULL for no padding rows. */
+int sdag_decode_attn_prealloc(const void* q, const void* k, const void* v, void* o,
+                              int64_t q_sb, int64_t q_sh,
+                              int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                              int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                              int64_t o_sb, int64_t o_sh,
+                              int B, int Hq, int Hkv, int S, int D, float scale,
+                              const int32_t* n_rows, const int32_t* valid_len, int pad_end,
+                              void* workspace, int64_t workspace_bytes, int out_dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Exact inner-product search.  Replaces  scores, indices = index.search(q, top_k)
  * (src/pipeline/retrieval/dense.py:82-84; the arithmetic of the reference is inside faiss).

@@ -45,6 +45,8 @@ struct DecodeParams {
     // (valid_len == nullptr: every key below S counts).
     const int32_t* valid_len;
     int pad_end;
+    // A preallocated cache: only rows below *n_rows (on the device, 1 <= *n_rows <= S) hold keys; nullptr: all S rows.
+    const int32_t* n_rows;
 };
 
 __device__ __forceinline__ float wave_max(float x) {
@@ -81,24 +83,25 @@ __global__ __launch_bounds__(64) void sdag_decode_main(const DecodeParams p) {
 #pragma unroll
     for (int j = 0; j < GW; ++j) { m[j] = -INFINITY; l[j] = 0.f; o0[j] = 0.f; o1[j] = 0.f; }
 
+    const int S = p.n_rows ? max(1, min(p.S, *p.n_rows)) : p.S;  // wave-uniform (a scalar load)
     const int g_begin = part * p.groups_per_part;
-    const int g_end = min(g_begin + p.groups_per_part, (p.S + 63) / 64);
-    const int hole_lo = p.valid_len ? p.valid_len[b] : p.S, hole_hi = p.valid_len ? p.pad_end : p.S;  // wave-uniform
+    const int g_end = min(g_begin + p.groups_per_part, (S + 63) / 64);
+    const int hole_lo = p.valid_len ? p.valid_len[b] : S, hole_hi = p.valid_len ? p.pad_end : S;  // wave-uniform
     for (int g = g_begin; g < g_end; ++g) {
         if (g * 64 >= hole_lo && g * 64 + 64 <= hole_hi) continue;  // 64 keys of padding
         const int key = g * 64 + lane;
-        const bool live = key < p.S && !(key >= hole_lo && key < hole_hi);
+        const bool live = key < S && !(key >= hole_lo && key < hole_hi);
         // ---- all loads of the group first: this lane's K row (16 x 16 bytes) and, coalesced, one 4-byte column pair
         // of each of the 64 V rows, so that the V rows travel while the scores are computed (rows past the end of
         // the sequence are clamped to the last key; their probability is 0)
-        const u32x4* krow = reinterpret_cast<const u32x4*>(kh + (int64_t)min(key, p.S - 1) * p.k_sl);
+        const u32x4* krow = reinterpret_cast<const u32x4*>(kh + (int64_t)min(key, S - 1) * p.k_sl);
         u32x4 kreg[16];
 #pragma unroll
         for (int ch = 0; ch < 16; ++ch) kreg[ch] = krow[ch];
         const unsigned* vbase = reinterpret_cast<const unsigned*>(vh) + lane;
         unsigned vw[64];
 #pragma unroll
-        for (int t = 0; t < 64; ++t) vw[t] = vbase[(int64_t)min(g * 64 + t, p.S - 1) * (p.v_sl / 2)];
+        for (int t = 0; t < 64; ++t) vw[t] = vbase[(int64_t)min(g * 64 + t, S - 1) * (p.v_sl / 2)];
         // ---- scores of this lane's key against the query rows
         float s[GW] = {0.f, 0.f, 0.f, 0.f};
         // the query words are re-read through the scalar cache for every group of keys: 256 of them do not fit
@@ -230,7 +233,7 @@ int decode_launch(const void* q, const void* k, const void* v, void* o,
                                 int64_t v_sb, int64_t v_sh, int64_t v_sl,
                                 int64_t o_sb, int64_t o_sh,
                                 int B, int Hq, int Hkv, int S, int Dh, float scale, const int32_t* valid_len, int pad_end,
-                                void* workspace, int64_t workspace_bytes_, int out_dtype, void* stream) {
+                                const int32_t* n_rows, void* workspace, int64_t workspace_bytes_, int out_dtype, void* stream) {
     if (Dh != D) return fail(SDAG_ERR_ARG, "head_dim %d not supported (only 128)", Dh);
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || S <= 0 || Hq % Hkv) return fail(SDAG_ERR_ARG, "bad B/Hq/Hkv/S");
     if (!(scale > 0.f)) return fail(SDAG_ERR_ARG, "scale must be positive");
@@ -253,6 +256,7 @@ int decode_launch(const void* q, const void* k, const void* v, void* o,
     p.part = (float*)workspace;
     p.valid_len = valid_len;
     p.pad_end = pad_end;
+    p.n_rows = n_rows;
     const int64_t blocks = (int64_t)B * Hkv * p.HG * p.n_parts;
     if (blocks > 0x7fffffff) return fail(SDAG_ERR_ARG, "grid too large");
     hipLaunchKernelGGL(sdag_decode_main, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, p);
@@ -271,7 +275,7 @@ extern "C" int sdag_decode_attn(const void* q, const void* k, const void* v, voi
                                 int B, int Hq, int Hkv, int S, int Dh, float scale,
                                 void* workspace, int64_t workspace_bytes_, int out_dtype, void* stream) {
     return decode_launch(q, k, v, o, q_sb, q_sh, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sh, B, Hq, Hkv, S, Dh, scale, nullptr, 0,
-                         workspace, workspace_bytes_, out_dtype, stream);
+                         nullptr, workspace, workspace_bytes_, out_dtype, stream);
 }
 
 extern "C" int sdag_decode_attn_padded(const void* q, const void* k, const void* v, void* o,
@@ -285,5 +289,19 @@ extern "C" int sdag_decode_attn_padded(const void* q, const void* k, const void*
     if (!valid_len) return fail(SDAG_ERR_ARG, "valid_len is NULL");
     if (pad_end < 0 || pad_end > S) return fail(SDAG_ERR_ARG, "pad_end outside [0, S]");
     return decode_launch(q, k, v, o, q_sb, q_sh, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sh, B, Hq, Hkv, S, Dh, scale, valid_len,
-                         pad_end, workspace, workspace_bytes_, out_dtype, stream);
+                         pad_end, nullptr, workspace, workspace_bytes_, out_dtype, stream);
+}
+
+extern "C" int sdag_decode_attn_prealloc(const void* q, const void* k, const void* v, void* o,
+                                         int64_t q_sb, int64_t q_sh,
+                                         int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                         int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                                         int64_t o_sb, int64_t o_sh,
+                                         int B, int Hq, int Hkv, int S, int Dh, float scale,
+                                         const int32_t* n_rows, const int32_t* valid_len, int pad_end,
+                                         void* workspace, int64_t workspace_bytes_, int out_dtype, void* stream) {
+    if (!n_rows) return fail(SDAG_ERR_ARG, "n_rows is NULL");
+    if (valid_len && (pad_end < 0 || pad_end > S)) return fail(SDAG_ERR_ARG, "pad_end outside [0, S]");
+    return decode_launch(q, k, v, o, q_sb, q_sh, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sh, B, Hq, Hkv, S, Dh, scale, valid_len,
+                         valid_len ? pad_end : 0, n_rows, workspace, workspace_bytes_, out_dtype, stream);
 }

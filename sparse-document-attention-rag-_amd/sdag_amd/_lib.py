@@ -47,6 +47,7 @@ SIGNATURES = {
     "sdag_decode_workspace_bytes": (i64, [i32, i32, i32]),
     "sdag_decode_attn": (i32, [vp, vp, vp, vp] + [i64] * 10 + [i32] * 5 + [ctypes.c_float, vp, i64, i32, vp]),
     "sdag_decode_attn_padded": (i32, [vp, vp, vp, vp] + [i64] * 10 + [i32] * 5 + [ctypes.c_float, vp, i32, vp, i64, i32, vp]),
+    "sdag_decode_attn_prealloc": (i32, [vp, vp, vp, vp] + [i64] * 10 + [i32] * 5 + [ctypes.c_float, vp, vp, i32, vp, i64, i32, vp]),
     "sdag_dense_workspace_bytes": (i64, [i32, i64, i32, i32]),
     "sdag_dense_topk": (i32, [vp, i32, vp, i64, i32, i32, vp, vp, i64, vp, i64, vp]),
     "sdag_topk_merge": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),

@@ -187,13 +187,16 @@ def sdag_attention_batch(query, key, value, batch: BatchDescriptor, scaling: Opt
 
 
 def decode_attention(query, key, value, scaling: Optional[float] = None, out_dtype: torch.dtype = torch.bfloat16,
-                     valid_len: Optional[torch.Tensor] = None, pad_end: int = 0) -> torch.Tensor:
+                     valid_len: Optional[torch.Tensor] = None, pad_end: int = 0,
+                     n_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Attention of ONE new token per sequence over the whole key/value cache (no mask): the attention of the
     reference's decode steps (src/pipeline/sparse_attention_RAG/SDAG.py:191-199).
 
     query [B, Hq, 1, D], key / value [B, Hkv, S, D] bf16 (any batch / head / row strides, D contiguous); returns
     [B, 1, Hq, D].  ``valid_len`` (int32 [B] on the device) with ``pad_end``: right-padded prompts decoded together --
-    cache rows [valid_len[b], pad_end) of sequence b are padding and take no part."""
+    cache rows [valid_len[b], pad_end) of sequence b are padding and take no part.  ``n_rows`` (one int32 on the
+    device): key / value are a preallocated cache of which only the first ``n_rows`` rows hold keys -- the count is read
+    by the kernel, so a captured step can be replayed while the cache fills."""
     if not (query.is_cuda and key.is_cuda and value.is_cuda):
         raise RuntimeError("decode_attention runs on the GPU only (no CPU fallback)")
     if query.dtype != torch.bfloat16 or key.dtype != torch.bfloat16 or value.dtype != torch.bfloat16:
@@ -221,12 +224,18 @@ def decode_attention(query, key, value, scaling: Optional[float] = None, out_dty
             out.stride(0), out.stride(2),
             B, Hq, Hkv, S, D, float(D ** -0.5 if scaling is None else scaling))
     tail = (ws.data_ptr(), ws.numel(), _lib.OUT_F32 if out_dtype == torch.float32 else _lib.OUT_BF16, _lib.stream_ptr(dev))
+    if valid_len is not None and (valid_len.dtype != torch.int32 or valid_len.device != dev or valid_len.numel() != B
+                                  or not valid_len.is_contiguous()):
+        raise ValueError("valid_len must be a contiguous int32 [B] tensor on the tensors' device")
+    if n_rows is not None and (n_rows.dtype != torch.int32 or n_rows.device != dev or n_rows.numel() != 1):
+        raise ValueError("n_rows must be one int32 on the tensors' device")
     with _on_device(dev):
-        if valid_len is None:
+        if n_rows is not None:
+            rc = lib.sdag_decode_attn_prealloc(*head, n_rows.data_ptr(), valid_len.data_ptr() if valid_len is not None else None,
+                                               int(pad_end), *tail)
+        elif valid_len is None:
             rc = lib.sdag_decode_attn(*head, *tail)
         else:
-            if valid_len.dtype != torch.int32 or valid_len.device != dev or valid_len.numel() != B or not valid_len.is_contiguous():
-                raise ValueError("valid_len must be a contiguous int32 [B] tensor on the tensors' device")
             rc = lib.sdag_decode_attn_padded(*head, valid_len.data_ptr(), int(pad_end), *tail)
     _lib.check(rc)
     return out

@@ -46,12 +46,16 @@ def active_descriptor(desc):
 
 
 @contextlib.contextmanager
-def active_padding(valid_len: torch.Tensor, pad_end: int):
-    """Single-token steps of right-padded prompts decoded together: cache rows [valid_len[b], pad_end) of sequence b
-    are padding (``valid_len``: int32 [B] on the model's device) and are left out of every decode-shaped attention
-    call on this thread inside the block."""
+def active_padding(valid_len: Optional[torch.Tensor], pad_end: int, n_rows: Optional[torch.Tensor] = None):
+    """How the key/value cache of the single-token steps inside the block (on this thread) is laid out.
+
+    ``valid_len`` (int32 [B] on the model's device) with ``pad_end``: right-padded prompts decoded together -- cache
+    rows [valid_len[b], pad_end) of sequence b are padding and are left out.  ``n_rows`` (one int32 on the device): the
+    cache is preallocated and only its first ``n_rows`` rows hold keys; the kernel reads the count, the caller keeps it
+    up to date (steps replayed from a captured graph).  With ``n_rows`` the caller vouches that this is ALL the masking
+    a step needs, so a mask tensor transformers built for the preallocated cache is not looked at."""
     prev = getattr(_state, "padding", None)
-    _state.padding = (valid_len, int(pad_end))
+    _state.padding = (valid_len, int(pad_end), n_rows)
     try:
         yield
     finally:
@@ -108,13 +112,15 @@ def sdag_hip_attention_forward(module, query, key, value, attention_mask, dropou
             out = out.to(query.dtype)
         return out, None
     padding = getattr(_state, "padding", None)
+    mask_ok = _mask_allows_everything(attention_mask) or (padding is not None and padding[2] is not None)
     if (query.shape[2] == 1 and key.shape[2] >= 1 and not dropout and _on_gpu(query) and query.shape[3] == 128
-            and query.shape[1] % key.shape[1] == 0 and _mask_allows_everything(attention_mask)):
+            and query.shape[1] % key.shape[1] == 0 and mask_ok):
         q, k, v = query, key, value
         if q.dtype != torch.bfloat16:
             q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
-        if padding is not None and padding[0].numel() == query.shape[0]:
-            out = decode_attention(q, k, v, scaling=scaling, out_dtype=torch.bfloat16, valid_len=padding[0], pad_end=padding[1])
+        if padding is not None and (padding[0] is None or padding[0].numel() == query.shape[0]):
+            out = decode_attention(q, k, v, scaling=scaling, out_dtype=torch.bfloat16, valid_len=padding[0], pad_end=padding[1],
+                                   n_rows=padding[2])
         else:
             out = decode_attention(q, k, v, scaling=scaling, out_dtype=torch.bfloat16)
         return (out if out.dtype == query.dtype else out.to(query.dtype)), None

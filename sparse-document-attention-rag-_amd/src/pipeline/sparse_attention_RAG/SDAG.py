@@ -10,6 +10,7 @@ tensor for callers that want it, expanded on the GPU from that same descriptor.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -117,10 +118,84 @@ def _decode_loop(model, tokenizer, input_ids, first_out, max_new_tokens: int) ->
     return tokenizer.decode(generated[0][prompt_len:], skip_special_tokens=True).strip()
 
 
+def decode_with_graph() -> bool:
+    """SDAG_DECODE_GRAPH=1: the cached single-token steps of ``generate_with_custom_mask`` /
+    ``run_rag_with_doc_isolation`` are replayed from one captured HIP graph (``_decode_loop_graphed``)."""
+    return os.environ.get("SDAG_DECODE_GRAPH", "0") == "1"
+
+
+def _replay_steps(dev, one_step, n_steps: int, after_step) -> None:
+    """Run ``one_step`` n_steps times: the first call eagerly (it also warms up every lazily built object), the
+    second under HIP graph capture, the rest as replays of that graph.  ``after_step()`` runs on the host after every
+    step (it may read results back) and returns True to stop."""
+    graph = None
+    for step in range(n_steps):
+        with torch.no_grad():
+            if step == 0:
+                one_step()
+            else:
+                if graph is None:
+                    torch.cuda.synchronize(dev)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        one_step()
+                graph.replay()
+        if after_step():
+            break
+
+
+def _static_cache_from(model, past, n_positions: int, capacity: int):
+    """A preallocated cache of ``capacity`` positions holding the ``n_positions`` positions of ``past`` (the prefill's
+    cache); transformers' StaticCache appends at a position it keeps on the device, so a captured step can be replayed."""
+    from transformers import StaticCache
+
+    cache = StaticCache(config=model.config, max_cache_len=capacity)
+    for idx, layer in enumerate(past.layers):
+        if layer.keys.shape[2] != n_positions:
+            raise ValueError(f"layer {idx} of the prefill's cache holds {layer.keys.shape[2]} positions, expected {n_positions}")
+        cache.update(layer.keys, layer.values, idx)
+    return cache
+
+
+def _decode_loop_graphed(model, tokenizer, input_ids, first_out, max_new_tokens: int) -> str:
+    """``_decode_loop`` with the single-token step captured ONCE as a HIP graph and replayed: a step is some hundreds
+    of small launches whose host cost exceeds their GPU time, and a replay is one launch.
+
+    Same tokens and the same stopping rule as SDAG.py:178-213 (the end-of-sequence test reads the token back after
+    every step, as the reference does).  What makes the step replayable: the cache is preallocated for
+    prompt + max_new_tokens + 1 positions, the token fed in and the number of cached positions live in device tensors
+    that the captured step itself updates, and the decode kernel reads that number on the device.
+    """
+    dev = input_ids.device
+    if dev.type != "cuda" or input_ids.size(0) != 1:
+        raise RuntimeError("graph-replayed decoding needs one prompt on a GPU")
+    prompt_len = input_ids.size(1)
+    cap = prompt_len + max_new_tokens + 1
+    cache = _static_cache_from(model, first_out.past_key_values, prompt_len, cap)
+    n_rows = torch.full((1,), prompt_len, dtype=torch.int32, device=dev)
+    tok = _sample(first_out.logits[:, -1, :]).clone()
+    tokens = [int(tok.item())]
+
+    def one_step():
+        n_rows.add_(1)  # the fed token's key and value are in the cache when a layer's attention runs
+        out = model(input_ids=tok, past_key_values=cache, use_cache=True)
+        tok.copy_(_sample(out.logits[:, -1, :]))
+
+    def after_step():
+        tokens.append(int(tok.item()))
+        return tokens[-1] == tokenizer.eos_token_id
+
+    with hf_attention.active_padding(None, 0, n_rows=n_rows):
+        _replay_steps(dev, one_step, max_new_tokens, after_step)
+    return tokenizer.decode(torch.tensor(tokens), skip_special_tokens=True).strip()
+
+
 def _generate_with_descriptor(model, tokenizer, input_ids, desc, max_new_tokens: int) -> str:
     with hf_attention.use_on_model(model):
         with torch.no_grad(), hf_attention.active_descriptor(desc):
             out = model(input_ids=input_ids, use_cache=True)  # masked prefill: the kernel path
+        if decode_with_graph():
+            return _decode_loop_graphed(model, tokenizer, input_ids, out, max_new_tokens)
         return _decode_loop(model, tokenizer, input_ids, out, max_new_tokens)
 
 
@@ -286,23 +361,43 @@ def _decode_loop_batched(model, tokenizer, ids: List[torch.Tensor], out, lengths
     dev = out.logits.device
     valid = torch.tensor(lengths, dtype=torch.int32, device=dev)
     last = torch.tensor([l - 1 for l in lengths], device=dev)
-    past = out.past_key_values
     tok = _sample(out.logits[torch.arange(n, device=dev), last])                      # [n, 1]
-    new_tokens = [tok]
+    new_tokens = [tok.clone()]
     finished = torch.zeros(n, dtype=torch.bool, device=dev)
     pos = valid.to(torch.long).unsqueeze(1)                                             # position of the token fed next
-    with hf_attention.active_padding(valid, l_max):
-        for _ in range(max_new_tokens):
-            with torch.no_grad():
-                step = model(input_ids=tok, past_key_values=past, position_ids=pos, use_cache=True)
-            past = step.past_key_values
-            tok = _sample(step.logits[:, -1, :])
-            new_tokens.append(tok)
-            pos = pos + 1
-            # the reference tests for EOS after appending the token (SDAG.py:208-211); a finished prompt stays finished
-            finished = finished | (tok[:, 0] == tokenizer.eos_token_id)
-            if bool(finished.all()):
-                break
+
+    def after_step():
+        # the reference tests for EOS after appending the token (SDAG.py:208-211); a finished prompt stays finished
+        nonlocal finished
+        new_tokens.append(tok.clone())
+        finished = finished | (tok[:, 0] == tokenizer.eos_token_id)
+        return bool(finished.all())
+
+    if decode_with_graph() and dev.type == "cuda":
+        # the same steps over a preallocated cache, captured once and replayed (see _decode_loop_graphed)
+        cache = _static_cache_from(model, out.past_key_values, l_max, l_max + max_new_tokens + 1)
+        n_rows = torch.full((1,), l_max, dtype=torch.int32, device=dev)
+        tok, pos = tok.clone(), pos.clone()
+
+        def one_step():
+            n_rows.add_(1)
+            step = model(input_ids=tok, past_key_values=cache, position_ids=pos, use_cache=True)
+            tok.copy_(_sample(step.logits[:, -1, :]))
+            pos.add_(1)
+
+        with hf_attention.active_padding(valid, l_max, n_rows=n_rows):
+            _replay_steps(dev, one_step, max_new_tokens, after_step)
+    else:
+        past = out.past_key_values
+        with hf_attention.active_padding(valid, l_max):
+            for _ in range(max_new_tokens):
+                with torch.no_grad():
+                    step = model(input_ids=tok, past_key_values=past, position_ids=pos, use_cache=True)
+                past = step.past_key_values
+                tok = _sample(step.logits[:, -1, :])
+                pos = pos + 1
+                if after_step():
+                    break
     gen = torch.cat(new_tokens, dim=1).cpu()
     answers = []
     for b in range(n):

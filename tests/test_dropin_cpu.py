@@ -245,7 +245,8 @@ def test_batched_entry_point_matches_reference_texts(SDAG, monkeypatch):
 
     # decode="batched": one model call per step for all prompts; the padding rows of the cache are left out by the
     # decode kernel (here: its fp32 restatement), every prompt keeps its own positions and its own end
-    def oracle_decode(q, k, v, scaling=None, out_dtype=torch.bfloat16, valid_len=None, pad_end=0):
+    def oracle_decode(q, k, v, scaling=None, out_dtype=torch.bfloat16, valid_len=None, pad_end=0, n_rows=None):
+        assert n_rows is None  # (a preallocated cache belongs to the graph-replayed loop, a GPU-only path)
         B, Hq, _, D = q.shape
         G = Hq // k.shape[1]
         out = torch.empty((B, 1, Hq, D), dtype=torch.float32)

@@ -77,6 +77,47 @@ def test_run_rag_with_doc_isolation_end_to_end():
         SDAG.TEMPERATURE = old_t
 
 
+def test_graph_replayed_decode_gives_the_reference_text(monkeypatch):
+    """SDAG_DECODE_GRAPH=1: the single-token steps are replayed from one captured HIP graph over a preallocated cache.
+    Greedy texts must equal what the REFERENCE's own function returned (tests/golden/make_golden_e2e.py), the decode
+    kernel must have run through the padded entry point (lengths read from the device), and a second answer from the
+    same model (new graph, new cache) must be right as well."""
+    SDAG = importlib.import_module("src.pipeline.sparse_attention_RAG.SDAG")
+    from sdag_amd import hf_attention
+
+    tok, g, path = load_e2e()
+    model, _ = load_e2e_model(g, path, device=DEV)
+    monkeypatch.setattr(SDAG, "TEMPERATURE", 0)
+    monkeypatch.setenv("SDAG_DECODE_GRAPH", "1")
+    seen = {"prealloc": 0, "other": 0}
+    real_decode = hf_attention.decode_attention
+
+    def counting_decode(*a, **kw):
+        seen["prealloc" if kw.get("n_rows") is not None else "other"] += 1
+        return real_decode(*a, **kw)
+
+    monkeypatch.setattr(hf_attention, "decode_attention", counting_decode)
+    for c in g["e2e"]:
+        ranker = FakeRanker(g["ranker_dim"], device=DEV)
+        text = SDAG.run_rag_with_doc_isolation(model, tok, c["query"], c["mal"], c["docs"], g["max_new_tokens"], DEV,
+                                               c["rank"], ranker, c["nbr_k"])
+        assert text == c["text"], c["name"]
+    # python-level calls: the eager first step and the captured one, per layer and answer; replays run no Python
+    nl = g["model_cfg"]["num_hidden_layers"]
+    assert seen["other"] == 0 and seen["prealloc"] == 2 * nl * len(g["e2e"])
+    # the batched entry point, all prompts decoded together from one captured step (attack rank 2, one neighbour for
+    # every prompt: a combination whose first-token margins are not near-ties on this random model)
+    batch_args = ([c["query"] for c in g["e2e"]], [c["mal"] for c in g["e2e"]], [c["docs"] for c in g["e2e"]], g["max_new_tokens"], DEV, 2)
+    singles = [SDAG.run_rag_with_doc_isolation(model, tok, c["query"], c["mal"], c["docs"], g["max_new_tokens"], DEV, 2,
+                                               FakeRanker(g["ranker_dim"], device=DEV), 1) for c in g["e2e"]]
+    seen["prealloc"] = 0
+    texts = SDAG.run_rag_with_doc_isolation_batch(model, tok, *batch_args, FakeRanker(g["ranker_dim"], device=DEV), 1, decode="batched")
+    assert texts == singles and seen["other"] == 0 and seen["prealloc"] == 2 * nl
+    monkeypatch.setenv("SDAG_DECODE_GRAPH", "0")
+    eager = SDAG.run_rag_with_doc_isolation_batch(model, tok, *batch_args, FakeRanker(g["ranker_dim"], device=DEV), 1, decode="batched")
+    assert eager == texts and seen["other"] > 0
+
+
 def test_batched_entry_point_on_gpu():
     """run_rag_with_doc_isolation_batch: one right-padded prefill (one batched kernel launch per layer, a descriptor per
     prompt) and per-prompt decoding.  Grouped by the fixture's (attack rank, neighbour count) its texts equal the

@@ -535,6 +535,36 @@ def test_decode_attention_with_padded_prompts():
     assert torch.equal(a, c)
 
 
+def test_decode_attention_over_a_preallocated_cache():
+    """A cache preallocated for S rows of which only the first n hold keys, n read by the kernel from device memory
+    (steps replayed from a captured graph): for several n, with and without padding rows, the result must be the one
+    of the plain / padded call on the first n rows, bit for bit; the rows beyond n are loud garbage; one launch
+    configuration serves every n (the count is only changed on the device between the calls)."""
+    import sdag_amd
+
+    B, Hq, Hkv, S, pad_end = 3, 32, 8, 700, 130
+    valid = [130, 17, 64]
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, Hq, 1, 128, generator=g).to(torch.bfloat16).to(DEV)
+    k = torch.randn(B, Hkv, S, 128, generator=g).to(torch.bfloat16).to(DEV)
+    v = (torch.randn(B, Hkv, S, 128, generator=g) * 2).to(torch.bfloat16).to(DEV)
+    vl = torch.tensor(valid, dtype=torch.int32, device=DEV)
+    n_rows = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for n in (131, 192, 193, 450, 700):
+        kg, vg = k.clone(), v.clone()
+        kg[:, :, n:] = 60.0
+        vg[:, :, n:] = float("nan")
+        n_rows.fill_(n)
+        a = sdag_amd.decode_attention(q, kg, vg, scaling=0.09, out_dtype=torch.float32, n_rows=n_rows)
+        b = sdag_amd.decode_attention(q, k[:, :, :n], v[:, :, :n], scaling=0.09, out_dtype=torch.float32)
+        assert torch.isfinite(a).all() and _rel_err(a.cpu(), b.cpu()) <= 1e-6, n   # (the split into parts differs with S)
+        a = sdag_amd.decode_attention(q, kg, vg, scaling=0.09, out_dtype=torch.float32, valid_len=vl, pad_end=pad_end, n_rows=n_rows)
+        b = sdag_amd.decode_attention(q, k[:, :, :n], v[:, :, :n], scaling=0.09, out_dtype=torch.float32, valid_len=vl, pad_end=pad_end)
+        assert torch.isfinite(a).all() and _rel_err(a.cpu(), b.cpu()) <= 1e-6, n
+    with pytest.raises(ValueError):
+        sdag_amd.decode_attention(q, k, v, n_rows=torch.zeros(1, dtype=torch.int64, device=DEV))
+
+
 def test_random_layout_sweep_masks_and_attention():
     """Forty more random prompts (0-8 documents of 0-120 tokens, gaps 0-3, neighbours with out-of-range and repeated
     ids, overlapping spans, wrong-length neighbour lists): the expanded descriptor equals the oracle's mask bit for bit

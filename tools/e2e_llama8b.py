@@ -84,6 +84,26 @@ with torch.no_grad():
         out = ours(); torch.cuda.synchronize()
         t0 = time.perf_counter(); decode_steps(out, ids); torch.cuda.synchronize()
         res["decode_ms_per_token_sdag_kernel"] = (time.perf_counter() - t0) / n_dec * 1e3
+        # the same steps replayed from one captured HIP graph over a preallocated cache (the drop-in's
+        # SDAG_DECODE_GRAPH=1 loop): per-token time from the difference of a long and a short run
+        SDAG = __import__("importlib").import_module("src.pipeline.sparse_attention_RAG.SDAG")
+        SDAG.TEMPERATURE = 0
+
+        class _Tok:
+            eos_token_id = -1
+
+            def decode(self, ids_, skip_special_tokens=True):
+                return ""
+
+        def graphed(n):
+            torch.cuda.synchronize(); t_ = time.perf_counter()
+            SDAG._decode_loop_graphed(model, _Tok(), ids, out, n); torch.cuda.synchronize()
+            return time.perf_counter() - t_
+        out = ours(); torch.cuda.synchronize()  # a fresh cache: the eager steps above appended to the other one
+        graphed(4)
+        t_short, t_long = graphed(8), graphed(8 + 64)
+        res["decode_ms_per_token_sdag_kernel_graph_replay"] = (t_long - t_short) / 64 * 1e3
+        res["decode_graph_setup_ms"] = (t_short - 8 * (t_long - t_short) / 64) * 1e3
         del out
         # batched prefill: 8 prompts, one launch per layer
         B = 8
@@ -112,6 +132,20 @@ with torch.no_grad():
         t0 = time.perf_counter(); decode_batch(outb); torch.cuda.synchronize()
         res["decode_ms_per_step_batch8_sdag_kernel"] = (time.perf_counter() - t0) / n_dec * 1e3
         res["decode_tokens_per_s_batch8_sdag_kernel"] = B * n_dec / (time.perf_counter() - t0)
+        # ... and the same batched steps replayed from one captured HIP graph (SDAG_DECODE_GRAPH=1)
+        with hf_attention.active_descriptor(batch):
+            outb = model(input_ids=bids, use_cache=True)
+        os.environ["SDAG_DECODE_GRAPH"] = "1"
+
+        def graphed_batch(n):
+            torch.cuda.synchronize(); t_ = time.perf_counter()
+            SDAG._decode_loop_batched(model, _Tok(), [None] * B, outb, [L] * B, n); torch.cuda.synchronize()
+            return time.perf_counter() - t_
+        graphed_batch(4)
+        t_short, t_long = graphed_batch(8), graphed_batch(8 + 64)
+        os.environ["SDAG_DECODE_GRAPH"] = "0"
+        res["decode_ms_per_step_batch8_sdag_kernel_graph_replay"] = (t_long - t_short) / 64 * 1e3
+        res["decode_tokens_per_s_batch8_sdag_kernel_graph_replay"] = B * 64 / (t_long - t_short)
         del outb
     addb = add.expand(B, 1, L, L)
     t, _ = sync_time(lambda: model(input_ids=bids, attention_mask=addb, use_cache=True).logits[:, -1], reps=2)
