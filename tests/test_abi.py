@@ -48,6 +48,12 @@ def test_error_reporting_without_gpu():
     assert attn(ptr=fake + 8) == _lib.SDAG_ERR_ARG and b"aligned" in lib.sdag_last_error()
     assert attn(L=1 << 20, o_sl=2048) == _lib.SDAG_ERR_ARG and b"slice of O" in lib.sdag_last_error()
     assert attn() == _lib.SDAG_ERR_DESC   # everything else in order: the missing descriptor is what is reported
+    # the decode entry points check their arguments before anything is launched as well
+    dec = (fake, fake, fake, fake, 4 * 128, 128, 8 * 128, 8 * 128, 128, 8 * 128, 8 * 128, 128, 4 * 128, 128, 1, 4, 1, 8, 128, 0.1)
+    assert lib.sdag_decode_attn_prealloc(*dec, None, None, 0, fake, 1 << 20, 0, None) == _lib.SDAG_ERR_ARG and b"n_rows" in lib.sdag_last_error()
+    assert lib.sdag_decode_attn_prealloc(*dec, fake, fake, 9, fake, 1 << 20, 0, None) == _lib.SDAG_ERR_ARG and b"pad_end" in lib.sdag_last_error()
+    assert lib.sdag_decode_attn_padded(*dec, None, 0, fake, 1 << 20, 0, None) == _lib.SDAG_ERR_ARG and b"valid_len" in lib.sdag_last_error()
+    assert lib.sdag_decode_attn_prealloc(*dec, fake, None, 0, None, 0, 0, None) == _lib.SDAG_ERR_CAPACITY
 
 
 def test_product_package_never_imports_the_oracle():

@@ -113,6 +113,16 @@ def test_graph_replayed_decode_gives_the_reference_text(monkeypatch):
     seen["prealloc"] = 0
     texts = SDAG.run_rag_with_doc_isolation_batch(model, tok, *batch_args, FakeRanker(g["ranker_dim"], device=DEV), 1, decode="batched")
     assert texts == singles and seen["other"] == 0 and seen["prealloc"] == 2 * nl
+    # sampling inside the captured step: runs, and the same seed gives the same answer twice
+    monkeypatch.setattr(SDAG, "TEMPERATURE", 0.7)
+    c = g["e2e"][0]
+    sampled = []
+    for _ in range(2):
+        torch.manual_seed(1234)
+        sampled.append(SDAG.run_rag_with_doc_isolation(model, tok, c["query"], c["mal"], c["docs"], g["max_new_tokens"], DEV, c["rank"],
+                                                       FakeRanker(g["ranker_dim"], device=DEV), c["nbr_k"]))
+    assert isinstance(sampled[0], str) and sampled[0] == sampled[1]
+    monkeypatch.setattr(SDAG, "TEMPERATURE", 0)
     monkeypatch.setenv("SDAG_DECODE_GRAPH", "0")
     eager = SDAG.run_rag_with_doc_isolation_batch(model, tok, *batch_args, FakeRanker(g["ranker_dim"], device=DEV), 1, decode="batched")
     assert eager == texts and seen["other"] > 0
