@@ -54,7 +54,7 @@ def synthetic_layout(sys_len, doc_lens, gap, qa_len):
 def mask_cases():
     rng = random.Random(1234)
     cases = []
-    # the survey's toy case, with and without neighbours
+    # a toy case (two documents, a few tokens each), with and without neighbours
     cases.append(dict(L=12, sys=3, spans=[(3, 5), (6, 9)], qa=10, nbr=None))
     cases.append(dict(L=12, sys=3, spans=[(3, 5), (6, 9)], qa=10, nbr=[[1], [0]]))
     # neighbour list of the wrong length is ignored wholesale

@@ -21,7 +21,7 @@ def test_mask_restatement_matches_reference_masks():
         assert int((m.sum(1) == 0).sum()) == c["empty_rows"]
 
 
-def test_survey_properties_of_the_mask():
+def test_structural_properties_of_the_mask():
     m = sdag_ref.mask_from_spans(12, 3, [(3, 5), (6, 9)], 10, [[1], [0]])
     assert not m[5].any() and not m[9].any()          # separator rows allow nothing
     assert m[3, 6:9].all()                            # neighbour span to the right of the row is visible
