@@ -568,7 +568,8 @@ def test_decode_attention_over_a_preallocated_cache():
 def test_random_layout_sweep_masks_and_attention():
     """Forty more random prompts (0-8 documents of 0-120 tokens, gaps 0-3, neighbours with out-of-range and repeated
     ids, overlapping spans, wrong-length neighbour lists): the expanded descriptor equals the oracle's mask bit for bit
-    and the attention output is within 1e-3 of the oracle's, for random head layouts and unit lengths."""
+    and the attention output is within 1e-3 of the oracle's, for random head layouts and unit lengths; the bf16 output
+    equals the rounded fp32 output."""
     import sdag_amd
     from oracle import sdag_ref
 
@@ -604,6 +605,12 @@ def test_random_layout_sweep_masks_and_attention():
         err = _rel_err(o, ref)
         worst = max(worst, err)
         assert err <= 1e-3, (case, err)
+        # the bf16 output (rows leave through the LDS staging image) is the rounding of the fp32 output, and rows
+        # beyond L are not touched
+        ob = torch.full((1, L + 2, Hq, 128), 3.0, dtype=torch.bfloat16, device=DEV)
+        sdag_amd.sdag_attention(q.to(DEV), k.to(DEV), v.to(DEV), d, out=ob[:, :L])
+        assert torch.equal(ob[:, :L].cpu(), o.to(torch.bfloat16)), case
+        assert (ob[:, L:] == 3.0).all(), case
     print("random sweep: worst rel err", worst)
 
 
