@@ -585,18 +585,24 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
             }
         }
     }
-    if (tid < n) ex[tid] = acc;
+    if (tid < n) {
+        const bool ok = acc == acc;  // a NaN score (infinities in the data) is never returned: it becomes a fill entry
+        ex[tid] = ok ? acc : -FLT_MAX;
+        if (!ok) cand[tid] = -1;
+    }
     __syncthreads();
-    // ---- this block's best k, sorted, as partial list g of query q
+    // ---- this block's best k, sorted, as partial list g of query q (equal entries - fills - ordered by position, so
+    // every rank is taken exactly once)
     const int64_t ob = ((int64_t)g * QT + q) * k;
     for (int c = tid; c < n; c += 256) {
         const float sc = ex[c];
         const int ic = cand[c];
         int rank = 0;
-        for (int j2 = 0; j2 < n; ++j2) rank += better(ex[j2], cand[j2], sc, ic) ? 1 : 0;
+        for (int j2 = 0; j2 < n; ++j2)
+            rank += (better(ex[j2], cand[j2], sc, ic) || (ex[j2] == sc && cand[j2] == ic && j2 < c)) ? 1 : 0;
         if (rank < k) {
             blk_s[ob + rank] = sc;
-            blk_i[ob + rank] = sc == sc ? ic : -1;
+            blk_i[ob + rank] = ic;
         }
     }
     if (tid < k && tid >= n) {
