@@ -113,7 +113,9 @@ int sdag_attn_fwd(const void* q, const void* k, const void* v, void* o,
  * sdag_attn_workspace_bytes(desc_host, B, Hq, Hkv) exceeds that size.  The call allocates and frees nothing.  All
  * calls on one GPU share that GPU's array: calls that overlap in time on one GPU (different streams or threads)
  * race; calls on one stream, or otherwise ordered, are safe.  Nothing in the array has to be cleared between calls:
- * every word a call reads was written earlier by that same call. */
+ * every word a call reads was written earlier by that same call.  The FIRST call on a device looks up the array's
+ * address there (hipGetSymbolAddress, which may load the library's code object: not a capturable operation), so make
+ * one eager call per device before calling under stream capture; every later call only launches kernels. */
 #define SDAG_STATIC_SCRATCH_BYTES (8 << 20)
 
 int sdag_attn_fwd_static(const void* q, const void* k, const void* v, void* o,

@@ -7,8 +7,10 @@ additive [1,1,L,L] mask (src/pipeline/sparse_attention_RAG/SDAG.py:167-176); her
 block-sparse descriptor set for the duration of the prefill, and no dense mask exists.
 
 The single-token decode steps (SDAG.py:191-211: one new position against the whole cache, no mask from the
-reference) run the key/value-streaming kernel ``sdag_decode_attn``.  Any other call (an ordinary causal prefill, a
-padded batch) is handed to transformers' stock SDPA attention unchanged.
+reference) run the key/value-streaming kernel ``sdag_decode_attn``.  While a descriptor is active every call with more
+than one query row must fit it (same batch, same length) or raises: the reference masks every prefill
+(SDAG.py:167-176), so none may fall through to plain causal attention.  Calls outside a descriptor (an ordinary causal
+prefill, a padded batch) are handed to transformers' stock SDPA attention unchanged.
 
 Masks: the function is registered with transformers' mask interface under SDPA's mask builder, which hands the
 layers ``None`` whenever nothing but causality has to be enforced and decides that ONCE per forward pass; the layers
@@ -73,44 +75,63 @@ def _mask_allows_everything(attention_mask) -> bool:
     return attention_mask is None
 
 
+def _additive_mask(desc: Descriptor, S: int, dtype, device) -> torch.Tensor:
+    """[S, S] additive mask (0 / finfo.min, SDAG.py:167-169) of one descriptor inside a padded length S; rows and
+    columns past the descriptor's own length allow nothing."""
+    add = torch.full((S, S), torch.finfo(dtype).min, dtype=dtype, device=device)
+    if desc.L:
+        add[:desc.L, :desc.L].masked_fill_(desc.materialize(device), 0)
+    return add
+
+
 def _dense_mask_fallback(module, query, key, value, desc, dropout, scaling, **kwargs):
-    """Prefill under a descriptor on a model the kernel does not cover (head_dim other than 128, query heads not a
-    multiple of key/value heads): SDPA under the dense mask expanded from the descriptor on the GPU."""
+    """Prefill under a descriptor (or a batch of them) on a model the kernel does not cover (head_dim other than 128,
+    query heads not a multiple of key/value heads): SDPA under the dense mask expanded from the descriptor on the GPU."""
     from transformers.integrations.sdpa_attention import sdpa_attention_forward
 
     if not query.is_cuda:
         raise RuntimeError("the SDAG attention path runs on the GPU only (no CPU fallback)")
-    dense = desc.materialize(query.device)
-    add = torch.zeros(dense.shape, dtype=query.dtype, device=query.device).masked_fill(~dense, torch.finfo(query.dtype).min)
-    return sdpa_attention_forward(module, query, key, value, add[None, None], dropout=dropout, scaling=scaling, **kwargs)
+    S = query.shape[2]
+    if isinstance(desc, BatchDescriptor):
+        add = torch.stack([_additive_mask(d, S, query.dtype, query.device) for d in desc.descs])[:, None]
+    else:
+        add = _additive_mask(desc, S, query.dtype, query.device)[None, None]
+    return sdpa_attention_forward(module, query, key, value, add, dropout=dropout, scaling=scaling, **kwargs)
+
+
+def _masked_prefill(module, query, key, value, desc, dropout, scaling, **kwargs):
+    """A prefill-shaped call (more than one query row) while a descriptor is active.  The reference applies its mask to
+    every prefill (SDAG.py:167-176), so a call the descriptor does not fit is an error: it must never run as plain
+    causal attention, which would silently drop the document isolation."""
+    B, Hq, Lq, D = query.shape
+    if Lq != key.shape[2]:
+        raise RuntimeError(f"SDAG prefill: {Lq} query rows against {key.shape[2]} keys while a mask descriptor is active "
+                           "(a prefill over an existing cache cannot be document-isolated by this descriptor)")
+    if isinstance(desc, BatchDescriptor):
+        if B != desc.B or Lq < desc.Lmax:
+            raise RuntimeError(f"SDAG prefill: batch of {B} x {Lq} tokens does not match the active batch descriptor "
+                               f"({desc.B} prompts, longest {desc.Lmax} tokens)")
+    elif Lq != desc.L:
+        raise RuntimeError(f"SDAG prefill: {Lq} tokens do not match the active descriptor (L = {desc.L})")
+    if dropout:
+        raise NotImplementedError("attention dropout is not supported by the SDAG kernel (inference only)")
+    if not (D == 128 and Hq % key.shape[1] == 0):  # (a CPU tensor: the kernel wrappers raise)
+        return _dense_mask_fallback(module, query, key, value, desc, dropout, scaling, **kwargs)
+    q, k, v = query, key, value
+    if q.dtype != torch.bfloat16:
+        q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+    if isinstance(desc, BatchDescriptor):
+        out = sdag_attention_batch(q, k, v, desc, scaling=scaling, out_dtype=torch.bfloat16)
+    else:
+        out = sdag_attention(q, k, v, desc, scaling=scaling, out_dtype=torch.bfloat16)
+    return (out if out.dtype == query.dtype else out.to(query.dtype)), None
 
 
 def sdag_hip_attention_forward(module, query, key, value, attention_mask, dropout: float = 0.0,
                                scaling: Optional[float] = None, **kwargs):
     desc = current_descriptor()
-    if isinstance(desc, BatchDescriptor):
-        # several prompts in one forward pass, right-padded to a common length, each with its own descriptor
-        if query.shape[0] == desc.B and query.shape[2] == key.shape[2] >= desc.Lmax and query.shape[3] == 128:
-            if dropout:
-                raise NotImplementedError("attention dropout is not supported by the SDAG kernel (inference only)")
-            q, k, v = query, key, value
-            if q.dtype != torch.bfloat16:
-                q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
-            out = sdag_attention_batch(q, k, v, desc, scaling=scaling, out_dtype=torch.bfloat16)
-            return (out if out.dtype == query.dtype else out.to(query.dtype)), None
-        desc = None
-    if desc is not None and query.shape[2] == key.shape[2] == desc.L:
-        if dropout:
-            raise NotImplementedError("attention dropout is not supported by the SDAG kernel (inference only)")
-        if not (query.shape[3] == 128 and query.shape[1] % key.shape[1] == 0):  # (a CPU tensor: sdag_attention raises)
-            return _dense_mask_fallback(module, query, key, value, desc, dropout, scaling, **kwargs)
-        q, k, v = query, key, value
-        if q.dtype != torch.bfloat16:
-            q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
-        out = sdag_attention(q, k, v, desc, scaling=scaling, out_dtype=torch.bfloat16)
-        if out.dtype != query.dtype:
-            out = out.to(query.dtype)
-        return out, None
+    if desc is not None and query.shape[2] > 1:
+        return _masked_prefill(module, query, key, value, desc, dropout, scaling, **kwargs)
     padding = getattr(_state, "padding", None)
     mask_ok = _mask_allows_everything(attention_mask) or (padding is not None and padding[2] is not None)
     if (query.shape[2] == 1 and key.shape[2] >= 1 and not dropout and _on_gpu(query) and query.shape[3] == 128

@@ -440,6 +440,43 @@ def test_generate_through_hf_hook_matches_reference_greedy_text(SDAG, monkeypatc
     assert SDAG.generate_with_custom_mask(model, Tok(), ids, mask, max_new_tokens=meta["max_new_tokens"]) == text
 
 
+def test_hook_never_runs_a_prefill_unmasked_while_a_descriptor_is_active(monkeypatch):
+    """The reference masks every prefill (SDAG.py:167-176).  While a descriptor (or a batch of them) is active, a
+    call with more than one query row that does not fit it raises instead of reaching stock causal attention; a call
+    the kernel cannot cover (head_dim 64) is refused on the CPU and masked through SDPA on a GPU."""
+    import sdag_amd
+    from sdag_amd import hf_attention
+    import transformers.integrations.sdpa_attention as sdpa_mod
+
+    def forbidden(*a, **kw):
+        raise AssertionError("stock attention reached while a descriptor was active")
+
+    monkeypatch.setattr(sdpa_mod, "sdpa_attention_forward", forbidden)
+    d40 = sdag_amd.from_spans(40, 5, [(5, 15), (16, 30)], 31)
+    d33 = sdag_amd.from_spans(33, 4, [(4, 12), (13, 25)], 26)
+    batch = sdag_amd.BatchDescriptor([d40, d33])
+
+    def qkv(B, L, S=None, D=128, Hq=4, Hkv=2):
+        S = L if S is None else S
+        return torch.zeros(B, Hq, L, D), torch.zeros(B, Hkv, S, D), torch.zeros(B, Hkv, S, D)
+
+    fwd = hf_attention.sdag_hip_attention_forward
+    with hf_attention.active_descriptor(d40):
+        for q, k, v in (qkv(1, 39), qkv(1, 41), qkv(1, 8, S=48)):       # shorter, longer, a chunk over a cache
+            with pytest.raises(RuntimeError, match="SDAG prefill"):
+                fwd(None, q, k, v, None, scaling=1.0)
+        with pytest.raises(RuntimeError, match="GPU only"):               # head_dim 64: the dense-mask route, never unmasked
+            fwd(None, *qkv(1, 40, D=64), None, scaling=1.0)
+    with hf_attention.active_descriptor(batch):
+        for q, k, v in (qkv(1, 40), qkv(3, 40), qkv(2, 39), qkv(2, 6, S=46)):  # wrong batch, too short, chunked
+            with pytest.raises(RuntimeError, match="SDAG prefill"):
+                fwd(None, q, k, v, None, scaling=1.0)
+        with pytest.raises(RuntimeError, match="GPU only"):
+            fwd(None, *qkv(2, 40, D=64), None, scaling=1.0)
+        with pytest.raises(NotImplementedError):
+            fwd(None, *qkv(2, 40), None, dropout=0.1, scaling=1.0)
+
+
 def test_overlay_on_reference_tree_when_present():
     """With this package in front of the reference on the path, the two hot-path modules resolve here and
     everything else (config, data models, utils) stays the reference's.  Skipped where the reference is absent."""

@@ -230,6 +230,93 @@ def test_attention_benchmark_head_layout():
     assert d2.n_uniform_rows == 10
 
 
+def test_attention_cfg4_benchmark_head_layout_batch():
+    """The long-context configuration (20 documents x 380 tokens, neighbours [(i+1)%K, (i+2)%K], L = 7710) at the
+    benchmark's head layout (32 query heads, 8 key/value heads) as a BATCH of two prompts -- the launch shape of
+    ``bench.py --config cfg4``: the second prompt ragged (document lengths 200-400) and with neighbour ids outside
+    [0, K) that the reference skips (SDAG.py:119-120).  fp32 output against the fp32 oracle, 1e-3 of max |ref| per
+    head; the bf16 output equals the rounded fp32 output; rows past a prompt's end stay untouched."""
+    import sdag_amd
+    from oracle import sdag_ref
+
+    Hq, Hkv, K = 32, 8, 20
+    spans, qa, L = synthetic_layout(60, [380] * K, 1, 30)
+    assert L == 7710
+    nbr = [[(i + 1) % K, (i + 2) % K] for i in range(K)]
+    lens = [int(x) for x in np.random.default_rng(4).integers(200, 401, size=K)]
+    spans2, qa2, L2 = synthetic_layout(60, lens, 1, 30)
+    nbr2 = [[(i + 1) % K, (i + 2) % K] for i in range(K)]
+    nbr2[3] = [K, 4]          # out of range: skipped
+    nbr2[7] = [-1, 9, 99]
+    nbr2[11] = []
+    Lmax = max(L, L2)
+    g = torch.Generator().manual_seed(4040)
+    q = torch.randn(2, Lmax, Hq, 128, generator=g).to(torch.bfloat16).transpose(1, 2)
+    k = torch.randn(2, Lmax, Hkv, 128, generator=g).to(torch.bfloat16).transpose(1, 2)
+    v = torch.randn(2, Lmax, Hkv, 128, generator=g).to(torch.bfloat16).transpose(1, 2)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    layouts = ((L, spans, qa, nbr), (L2, spans2, qa2, nbr2))
+    descs = [sdag_amd.from_spans(Lb, 60, sp, qb, nb, max_items_per_unit=64) for Lb, sp, qb, nb in layouts]
+    batch = sdag_amd.BatchDescriptor(descs)
+    o32 = torch.full((2, Lmax, Hq, 128), 7.0, dtype=torch.float32, device=DEV)
+    from sdag_amd.attention import BoundBatchAttention
+    BoundBatchAttention(qd, kd, vd, batch, o32)()
+    o16 = sdag_amd.sdag_attention_batch(qd, kd, vd, batch).cpu()
+    o32 = o32.cpu()
+    for b, (Lb, sp, qb, nb) in enumerate(layouts):
+        mask_np = sdag_ref.mask_from_spans(Lb, 60, sp, qb, nb)
+        assert np.array_equal(descs[b].materialize(DEV).cpu().numpy(), mask_np)
+        ref = sdag_ref.masked_attention(q[b:b + 1, :, :Lb], k[b:b + 1, :, :Lb], v[b:b + 1, :, :Lb],
+                                        torch.from_numpy(mask_np), 128 ** -0.5)
+        err = _rel_err(o32[b:b + 1, :Lb], ref)
+        print(f"cfg4 batch prompt {b}: L {Lb}, rel err {err:.2e}")
+        assert err <= 1e-3
+        assert torch.equal(o16[b, :Lb], o32[b, :Lb].to(torch.bfloat16))
+        assert bool((o32[b, Lb:] == 7.0).all())
+
+
+def test_prefill_on_unsupported_head_dim_is_masked_not_causal():
+    """A model whose head_dim the kernel does not cover (64) under an active descriptor / batch of descriptors: the
+    hook runs SDPA under the dense mask expanded from the descriptor, never plain causal attention."""
+    import sdag_amd
+    from oracle import sdag_ref
+    from sdag_amd import hf_attention
+
+    spans, qa, L = synthetic_layout(7, [30, 18, 41], 1, 9)
+    nbr = [[1], [2], []]
+    spans2, qa2, L2 = synthetic_layout(5, [22, 35], 2, 6)
+    g = torch.Generator().manual_seed(64)
+    q = torch.randn(2, 4, L, 64, generator=g)
+    k = torch.randn(2, 2, L, 64, generator=g)
+    v = torch.randn(2, 2, L, 64, generator=g)
+    d1 = sdag_amd.from_spans(L, 7, spans, qa, nbr)
+    d2 = sdag_amd.from_spans(L2, 5, spans2, qa2, None)
+    m1 = torch.from_numpy(sdag_ref.mask_from_spans(L, 7, spans, qa, nbr))
+    m2 = torch.from_numpy(sdag_ref.mask_from_spans(L2, 5, spans2, qa2, None))
+
+    class Mod:  # what transformers' SDPA wrapper reads from the attention module
+        num_key_value_groups = 2
+        is_causal = True
+        training = False
+
+    with hf_attention.active_descriptor(d1):
+        o, _ = hf_attention.sdag_hip_attention_forward(Mod(), q[:1].to(DEV), k[:1].to(DEV), v[:1].to(DEV), None, scaling=0.125)
+    ref1 = sdag_ref.masked_attention(q[:1], k[:1], v[:1], m1, 0.125)
+    # rows that allow nothing are left out: what a fused SDPA kernel returns for a row masked with finfo.min everywhere
+    # is that kernel's business (the reference on this GPU would get the same), the isolation of the others is the point
+    r1, r2 = m1.any(1), m2.any(1)
+    assert _rel_err(o.cpu()[:, r1], ref1[:, r1]) <= 1e-4
+    causal = sdag_ref.masked_attention(q[:1], k[:1], v[:1], torch.ones(L, L).tril().bool(), 0.125)
+    assert _rel_err(causal[:, r1], ref1[:, r1]) > 1e-2        # the two differ, so the comparison above means something
+    with hf_attention.active_descriptor(sdag_amd.BatchDescriptor([d1, d2])):
+        ob, _ = hf_attention.sdag_hip_attention_forward(Mod(), q.to(DEV), k.to(DEV), v.to(DEV), None, scaling=0.125)
+    ob = ob.cpu()
+    assert _rel_err(ob[:1, r1], ref1[:, r1]) <= 1e-4
+    ref2 = sdag_ref.masked_attention(q[1:, :, :L2], k[1:, :, :L2], v[1:, :, :L2], m2, 0.125)
+    assert _rel_err(ob[1:, :L2][:, r2], ref2[:, r2]) <= 1e-4
+    assert bool(torch.isfinite(ob).all())
+
+
 def test_pipeline_chain_sharded_hybrid_selection_generation():
     """The flow of the end-to-end configuration at small scale, through the modules that carry the reference's names:
     corpus sharded over the ranks of an RCCL group (one rank here) -> DenseRetriever -> HybridRetriever (a lexical

@@ -535,6 +535,44 @@ def test_decode_attention_with_padded_prompts():
     assert torch.equal(a, c)
 
 
+def test_decode_attention_padding_up_to_the_last_row_and_not_a_number_in_the_padding():
+    """Padding that reaches the last cache row (pad_end == S, S not a multiple of 64, a sequence whose live keys end
+    before the last 64-key window), a preallocated cache whose row count equals pad_end, and NaN / Inf in the padding
+    rows of K and V: padding rows take no part, so the output is finite and equals the fp32 softmax over the live keys."""
+    import sdag_amd
+
+    Hq, Hkv = 8, 2
+    G = Hq // Hkv
+    for S, pad_end, valid in ((200, 200, [200, 3, 128, 129, 64]), (333, 333, [1, 333, 192, 70, 256]), (130, 130, [65, 64, 1, 130, 2])):
+        B = len(valid)
+        g = torch.Generator().manual_seed(S)
+        q = torch.randn(B, Hq, 1, 128, generator=g).to(torch.bfloat16)
+        k = torch.randn(B, Hkv, S, 128, generator=g).to(torch.bfloat16)
+        v = (torch.randn(B, Hkv, S, 128, generator=g) * 2).to(torch.bfloat16)
+        ref = torch.empty(B, 1, Hq, 128)
+        for b in range(B):
+            kk = k[b, :, :valid[b]].float().repeat_interleave(G, dim=0)
+            vv = v[b, :, :valid[b]].float().repeat_interleave(G, dim=0)
+            ref[b, 0] = (torch.softmax(q[b].float() @ kk.transpose(1, 2) * 0.09, dim=-1) @ vv)[:, 0]
+            k[b, :, valid[b]:pad_end] = float("nan")
+            v[b, :, valid[b]:pad_end:2] = float("nan")
+            v[b, :, valid[b] + 1:pad_end:2] = float("inf")
+        vl = torch.tensor(valid, dtype=torch.int32, device=DEV)
+        o = sdag_amd.decode_attention(q.to(DEV), k.to(DEV), v.to(DEV), scaling=0.09, out_dtype=torch.float32, valid_len=vl,
+                                      pad_end=pad_end).cpu()
+        assert torch.isfinite(o).all(), (S, valid)
+        assert _rel_err(o, ref) <= 1e-3, (S, valid)
+        # the same cache preallocated for more rows, the row count (== pad_end) read on the device
+        cap = S + 100
+        kc = torch.full((B, Hkv, cap, 128), float("nan"), dtype=torch.bfloat16)
+        vc = torch.full((B, Hkv, cap, 128), float("nan"), dtype=torch.bfloat16)
+        kc[:, :, :S], vc[:, :, :S] = k, v
+        n_rows = torch.full((1,), pad_end, dtype=torch.int32, device=DEV)
+        o2 = sdag_amd.decode_attention(q.to(DEV), kc.to(DEV), vc.to(DEV), scaling=0.09, out_dtype=torch.float32, valid_len=vl,
+                                       pad_end=pad_end, n_rows=n_rows).cpu()
+        assert torch.isfinite(o2).all() and _rel_err(o2, ref) <= 1e-3, (S, valid)
+
+
 def test_decode_attention_over_a_preallocated_cache():
     """A cache preallocated for S rows of which only the first n hold keys, n read by the kernel from device memory
     (steps replayed from a captured graph): for several n, with and without padding rows, the result must be the one
