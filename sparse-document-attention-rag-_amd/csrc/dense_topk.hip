@@ -9,8 +9,11 @@
 // v_mfma_f32_32x32x2_f32 computes D = fma(a1, b1, fma(a0, b0, C)) per output element, so chaining the
 // accumulator through d/2 MFMAs in dimension order reproduces that chain bit for bit.
 //
-// Scan kernel: every workgroup (4 waves) owns a contiguous stripe of corpus rows and walks it in tiles of
-// 128 rows; wave w multiplies rows 32 w .. 32 w + 31 of the tile against up to 32 queries.  Corpus and query
+// Scan kernel: every workgroup owns a contiguous stripe of corpus rows and walks it in tiles of 128 rows against up
+// to 32 NQB queries per pass over the corpus (NQB = 1, 2 or 4, chosen from the number of queries: a staged corpus
+// tile is multiplied against NQB blocks of 32 queries, so 128 queries cost one read of the corpus, not four).  With
+// 4 waves (NQB = 1) wave w multiplies rows 32 w .. 32 w + 31 of the tile against the one query block; with 8 waves
+// waves w and w + 4 share those rows and split the query blocks.  Corpus and query
 // slices of 32 dimensions are brought into a 3-stage LDS ring by LDS-DMA (global_load_lds_dwordx4, one
 // 1 KiB piece per wave instruction, 128-byte source lines, XOR-swizzled through the SOURCE address so that
 // the later ds_read_b128 fragment reads are bank-conflict free).  Loads run two stages ahead of the MFMAs
@@ -22,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <type_traits>
 #include <climits>
 
 #include "common.h"
@@ -37,7 +41,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 #define SDAG_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define SDAG_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-constexpr int QT = 32;                      // queries per pass
+constexpr int QT = 32;                      // queries per query block (one MFMA tile wide)
 constexpr int TR = 128;                     // corpus rows per tile
 constexpr int KC = 32;                      // fp32 dimensions per stage (128 bytes of a row)
 constexpr int KC16 = 64;                    // bf16 dimensions per stage (the same 128 bytes)
@@ -46,21 +50,68 @@ constexpr int KC16 = 64;                    // bf16 dimensions per stage (the sa
 #define SDAG_SCAN_WG_PER_CU 2
 #endif
 constexpr int NST = SDAG_SCAN_NST;          // LDS ring depth: loads run NST - 1 stages ahead of the MFMAs
-constexpr int SCAN_WAIT = 5 * (NST - 2);    // vector-memory operations of the stages after the current one (5 per stage and wave)
 constexpr int C_STAGE = TR * KC * 4;        // 16 KiB
-constexpr int Q_STAGE = QT * KC * 4;        // 4 KiB
-constexpr int STAGE_BYTES = C_STAGE + Q_STAGE;
-constexpr int CAP = 64;                     // candidate list capacity per query
+constexpr int Q_STAGE = QT * KC * 4;        // 4 KiB per query block
 constexpr int PUSH_MAX = 32;                // most entries one filter round can append to one list
 constexpr int MAX_K = 32;
 constexpr int MAX_WG = 512;                 // stripe lists the merge and rescoring kernels can take
-constexpr int SCAN_WG = 256 * SDAG_SCAN_WG_PER_CU;  // workgroups of the scan: what the chip holds at once
-constexpr int OFF_CS = NST * STAGE_BYTES;           // float cand_s[QT][CAP]
-constexpr int OFF_CI = OFF_CS + QT * CAP * 4;       // int   cand_i[QT][CAP]
-constexpr int OFF_CNT = OFF_CI + QT * CAP * 4;      // int   cnt[QT]
-constexpr int OFF_TS = OFF_CNT + QT * 4;            // float thr_s[QT]
-constexpr int OFF_TI = OFF_TS + QT * 4;             // int   thr_i[QT]
-constexpr int SCAN_LDS = OFF_TI + QT * 4;
+constexpr int SCAN_WG = 256 * SDAG_SCAN_WG_PER_CU;  // workgroups of the narrow scan: what the chip holds at once
+#ifndef SDAG_SCAN_EXP
+#define SDAG_SCAN_EXP 0   // timing-only builds: 1 no filtering, 2 no MFMAs, 4 no query pieces, 8 no corpus pieces
+#endif
+constexpr int MAX_NQB = 4;                  // query blocks of the widest scan
+constexpr int WIDE_KS = 16;                 // longest stripe list the widest scan keeps (its lists are shorter: LDS)
+#ifndef SDAG_SCAN_NSTC
+#define SDAG_SCAN_NSTC 4
+#endif
+#ifndef SDAG_SCAN_QDMA
+#define SDAG_SCAN_QDMA 1   // 1: the wide scans bring their query slabs by LDS-DMA as well (waves 4-7), 0: through registers
+#endif
+#define SDAG_SCAN_NSTQ 2
+static_assert(SCAN_WG <= MAX_WG, "the rescoring kernel holds one maximum per stripe in MAX_WG / 64 registers");
+static_assert(MAX_WG % 64 == 0, "stripe maxima are held 64 per register");
+
+// Geometry of one scan variant: NQB query blocks, NW waves.
+//   NW = 4: every wave issues corpus and query pieces of a stage into ONE ring of NST stages (two workgroups per
+//           compute unit keep 4 x 16 KiB of corpus in flight there).
+//   NW = 8: one workgroup per compute unit, so the corpus ring is deeper (NSTC stages); the query slabs, which come
+//           from the L2, sit in a shallow ring of their own (NSTQ).  Waves 0-3 issue only corpus pieces and waves 4-7
+//           only query pieces: the s_waitcnt counter is per wave and in issue order, so a wave that issued both could
+//           not wait for a recent query piece without also waiting for every older corpus piece.
+template <int NQB, int NW>
+struct ScanCfg {
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert(NQB % (NW / 4) == 0, "the query blocks are split over the wave groups");
+    static constexpr bool SPLIT = NW == 8;               // separate rings and loader roles
+    static constexpr int QTW = QT * NQB;                 // queries per pass
+    static constexpr int QPW = NQB / (NW / 4);           // query blocks per wave
+    static constexpr int NSTC = SPLIT ? SDAG_SCAN_NSTC : NST;
+    static constexpr int NSTQ = SPLIT ? SDAG_SCAN_NSTQ : NST;
+    static constexpr int Q_SLAB = NQB * Q_STAGE;
+    static constexpr int C_STRIDE = SPLIT ? C_STAGE : C_STAGE + Q_SLAB;   // distance of consecutive corpus stages
+    static constexpr int Q_STRIDE = SPLIT ? Q_SLAB : C_STAGE + Q_SLAB;
+    static constexpr int Q_BASE = SPLIT ? NSTC * C_STAGE : C_STAGE;
+    static constexpr int RING = SPLIT ? NSTC * C_STAGE + NSTQ * Q_SLAB : NST * (C_STAGE + Q_SLAB);
+    static constexpr int PPW_C = SPLIT ? 4 : 4;          // corpus pieces (1 KiB) a loading wave issues per stage
+    static constexpr int PPW_Q = NQB;                    // query pieces a loading wave issues per stage
+    // vector-memory operations a wave may leave in flight when it needs stage s: those of the later stages
+    static constexpr int WAIT_C = SPLIT ? PPW_C * (NSTC - 2) : (PPW_C + PPW_Q) * (NST - 2);
+    // candidate list capacity per query: 64, or what the LDS leaves (a list is compacted when it could overflow in the
+    // next filter round, so a short list is compacted after every few survivors)
+    static constexpr int CAP_ROOM = (160 * 1024 - RING - 3 * QTW * 4) / (QTW * 8);
+    static constexpr int CAP = CAP_ROOM < 64 ? CAP_ROOM : 64;
+    static_assert(CAP >= (NQB == MAX_NQB ? WIDE_KS : MAX_K) + PUSH_MAX, "a list holds what is kept plus one round of survivors");
+    static constexpr int LPW = QTW / NW;                 // lists a wave looks after
+    static constexpr int OFF_CS = RING;                  // float cand_s[QTW][CAP]
+    static constexpr int OFF_CI = OFF_CS + QTW * CAP * 4;  // int   cand_i[QTW][CAP]
+    static constexpr int OFF_CNT = OFF_CI + QTW * CAP * 4; // int   cnt[QTW]
+    static constexpr int OFF_TS = OFF_CNT + QTW * 4;     // float thr_s[QTW]
+    static constexpr int OFF_TI = OFF_TS + QTW * 4;      // int   thr_i[QTW]
+    static constexpr int LDS = OFF_TI + QTW * 4;
+    static constexpr int WG_PER_CU = SPLIT ? 1 : SDAG_SCAN_WG_PER_CU;
+    static_assert(LDS <= 160 * 1024, "LDS of a compute unit");
+    static_assert(LPW <= 64, "a wave checks its lists' lengths one per lane");
+};
 
 __device__ __forceinline__ bool better(float s, int64_t i, float s2, int64_t i2) {
     return (s > s2) || (s == s2 && i < i2);
@@ -78,8 +129,21 @@ __device__ __forceinline__ void swap_halves(float& x, float& y) {
     asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
 }
 
+// Order-preserving map of a float's bits to an unsigned integer (larger float = larger key; -inf lowest of all values
+// that occur here), and back.
+__device__ __forceinline__ unsigned float_key(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(unsigned key) {
+    return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+}
+
 // One wave reduces list j to its best min(n, k) entries, sorted best first, and refreshes the threshold.
+template <class CFG>
 __device__ __forceinline__ void compact_list(unsigned char* smem, int j, int k, int lane) {
+    constexpr int CAP = CFG::CAP, OFF_CS = CFG::OFF_CS, OFF_CI = CFG::OFF_CI, OFF_CNT = CFG::OFF_CNT, OFF_TS = CFG::OFF_TS,
+                  OFF_TI = CFG::OFF_TI;
     float* cs = reinterpret_cast<float*>(smem + OFF_CS) + j * CAP;
     int* ci = reinterpret_cast<int*>(smem + OFF_CI) + j * CAP;
     int* cnt = reinterpret_cast<int*>(smem + OFF_CNT);
@@ -107,12 +171,18 @@ __device__ __forceinline__ void compact_list(unsigned char* smem, int j, int k, 
 // BF16 = false: the exact scan described above.  BF16 = true: the same walk over bf16 copies of corpus and queries
 // (64 dimensions per 128-byte stage, one v_mfma_f32_32x32x16_bf16 per 16 dimensions): approximate scores, used only
 // to pick candidates for exact rescoring.  run_flag (optional): the kernel does nothing when *run_flag == 0.
-template <bool BF16>
-__global__ __launch_bounds__(256, SDAG_SCAN_WG_PER_CU) void dense_scan(const void* __restrict__ Qv, int nq, const void* __restrict__ Cv,
+// Partial lists: part[(stripe * QTW + query) * k + t].
+template <bool BF16, int NQB, int NW>
+__global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW>::WG_PER_CU)) void dense_scan(const void* __restrict__ Qv, int nq, const void* __restrict__ Cv,
                                                      int64_t N, int d, int k, int rows_per_wg,
                                                      float* __restrict__ part_s, int* __restrict__ part_i,
-                                                     const int* __restrict__ run_flag) {
+                                                     const int* __restrict__ run_flag, int q_row_bytes, int q_kc_bytes) {
+    // Query j's 128 bytes of stage kc sit at Q + j * q_row_bytes + kc * q_kc_bytes (row-major queries: d * element size
+    // and 128; slab-major, see query_prepare_kernel: 128 and 128 * queries per pass).
     if (run_flag && *run_flag == 0) return;
+    using CFG = ScanCfg<NQB, NW>;
+    constexpr int QTW = CFG::QTW, QPW = CFG::QPW, CAP = CFG::CAP, LPW = CFG::LPW;
+    constexpr int OFF_CS = CFG::OFF_CS, OFF_CI = CFG::OFF_CI, OFF_CNT = CFG::OFF_CNT, OFF_TS = CFG::OFF_TS, OFF_TI = CFG::OFF_TI;
     constexpr int KCE = BF16 ? KC16 : KC;  // elements per stage
     constexpr int ES = BF16 ? 2 : 4;       // bytes per element
     const unsigned char* Q = reinterpret_cast<const unsigned char*>(Qv);
@@ -122,134 +192,243 @@ __global__ __launch_bounds__(256, SDAG_SCAN_WG_PER_CU) void dense_scan(const voi
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __builtin_assume(w >= 0 && w < NW);
+    const int rg = w & 3, qg = w >> 2;  // the wave's 32 rows of a tile, its group of query blocks
     const int64_t wg_row0 = (int64_t)blockIdx.x * rows_per_wg;
     const int64_t wg_rows = min((int64_t)rows_per_wg, N - wg_row0);
     const int ntile = (int)((wg_rows + TR - 1) / TR);
     const int nkc = d / KCE;
     const int S = ntile * nkc;
 
-    if (tid < QT) {
-        reinterpret_cast<int*>(smem + OFF_CNT)[tid] = 0;
-        reinterpret_cast<float*>(smem + OFF_TS)[tid] = -INFINITY;
-        reinterpret_cast<int*>(smem + OFF_TI)[tid] = INT_MAX;
+    for (int j = tid; j < QTW; j += 64 * NW) {
+        reinterpret_cast<int*>(smem + OFF_CNT)[j] = 0;
+        reinterpret_cast<float*>(smem + OFF_TS)[j] = -INFINITY;
+        reinterpret_cast<int*>(smem + OFF_TI)[j] = INT_MAX;
     }
     lds_barrier();
 
     // ---- LDS-DMA geometry.  A wave instruction writes 1 KiB = 8 rows x 128 B; lane -> (row lane >> 3,
-    // physical chunk lane & 7); the source chunk is physical ^ ((row >> 1) & 7).
+    // physical chunk lane & 7); the source chunk is physical ^ ((row >> 1) & 7).  A corpus stage is 16 pieces (rows
+    // 8 c .. 8 c + 7 of the tile), a query slab 4 NQB pieces (queries 8 c ..).
     const int dr = lane >> 3, dc = lane & 7;
-    auto issue = [&](int s) {
+    auto issue_c = [&](int s, int c) {  // corpus piece c of stage s
+        if (SDAG_SCAN_EXP & 8) return;
         s = s < S ? s : S - 1;  // past the end: reload the last stage into the free slot (keeps vmcnt counts fixed)
         const int tile = s / nkc, kc = s - tile * nkc;
-        unsigned char* sb = smem + (s % NST) * STAGE_BYTES;
-        const int64_t trow0 = wg_row0 + (int64_t)tile * TR + w * 32;
+        unsigned char* sb = smem + (s % CFG::NSTC) * CFG::C_STRIDE;
+        const int rl = c * 8 + dr;  // row inside the tile (the swizzle only looks at its low bits)
+        int64_t row = wg_row0 + (int64_t)tile * TR + rl;
+        row = row < N ? row : N - 1;
+        const int csrc = dc ^ ((rl >> 1) & 7);
+        const unsigned char* src = C + (row * d + kc * KCE) * ES + csrc * 16;
+        __builtin_amdgcn_global_load_lds(SDAG_GLB_PTR(src), SDAG_LDS_PTR(sb + c * 1024), 16, 0, 0);
+    };
+    auto issue_q = [&](int s, int c) {  // query piece c of stage s
+        if (SDAG_SCAN_EXP & 4) return;
+        s = s < S ? s : S - 1;
+        const int kc = s % nkc;
+        unsigned char* sb = smem + CFG::Q_BASE + (s % CFG::NSTQ) * CFG::Q_STRIDE;
+        int j = c * 8 + dr;
+        const int csrc = dc ^ ((j >> 1) & 7);
+        j = j < nq ? j : nq - 1;
+        const unsigned char* src = Q + (int64_t)j * q_row_bytes + (int64_t)kc * q_kc_bytes + csrc * 16;
+        __builtin_amdgcn_global_load_lds(SDAG_GLB_PTR(src), SDAG_LDS_PTR(sb + c * 1024), 16, 0, 0);
+    };
+    // what this wave issues for the stage that is `ahead` stages in front of stage s
+    auto issue_corpus = [&](int s) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int rl = n * 8 + dr;  // row inside the wave's 32
-            int64_t row = trow0 + rl;
-            row = row < N ? row : N - 1;
-            const int csrc = dc ^ ((rl >> 1) & 7);
-            const unsigned char* src = C + (row * d + kc * KCE) * ES + csrc * 16;
-            __builtin_amdgcn_global_load_lds(SDAG_GLB_PTR(src), SDAG_LDS_PTR(sb + (w * 4 + n) * 1024), 16, 0, 0);
-        }
-        {
-            int j = w * 8 + dr;
+        for (int n = 0; n < CFG::PPW_C; ++n) issue_c(s, (w & 3) * 4 + n);
+    };
+    auto issue_queries = [&](int s) {
+#pragma unroll
+        for (int n = 0; n < CFG::PPW_Q; ++n) issue_q(s, (w & 3) * NQB + n);
+    };
+    // The same pieces through registers (waves 4-7 of the wide scans): requested when a stage starts, written to the
+    // slab of the next stage when it ends.  The fill rate of LDS-DMA is about one piece per 100 cycles and compute
+    // unit whatever the source, so query pieces sent that way would halve the corpus rate.
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    u32x4 qreg[CFG::PPW_Q];
+    auto load_queries = [&](int s) {
+        if (SDAG_SCAN_EXP & 4) return;
+        s = s < S ? s : S - 1;
+        const int kc = s % nkc;
+#pragma unroll
+        for (int n = 0; n < CFG::PPW_Q; ++n) {
+            int j = ((w & 3) * NQB + n) * 8 + dr;
             const int csrc = dc ^ ((j >> 1) & 7);
             j = j < nq ? j : nq - 1;
-            const unsigned char* src = Q + ((int64_t)j * d + kc * KCE) * ES + csrc * 16;
-            __builtin_amdgcn_global_load_lds(SDAG_GLB_PTR(src), SDAG_LDS_PTR(sb + C_STAGE + w * 1024), 16, 0, 0);
+            qreg[n] = *reinterpret_cast<const u32x4*>(Q + (int64_t)j * q_row_bytes + (int64_t)kc * q_kc_bytes + csrc * 16);
         }
+    };
+    auto store_queries = [&](int s) {
+        unsigned char* sb = smem + CFG::Q_BASE + (s % CFG::NSTQ) * CFG::Q_STRIDE;
+#pragma unroll
+        for (int n = 0; n < CFG::PPW_Q; ++n) *reinterpret_cast<u32x4*>(sb + ((w & 3) * NQB + n) * 1024 + lane * 16) = qreg[n];
     };
 
     const int r = lane & 31, h = lane >> 5;
     const int swz = (r >> 1) & 7;
-    const int a_off = (w * 32 + r) * 128;
-    const int b_off = C_STAGE + r * 128;
+    const int a_off = (rg * 32 + r) * 128;
+    const int b_off = (qg * QPW * 32 + r) * 128;
 
-    f32x16 acc;
+    f32x16 acc[QPW];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int qb = 0; qb < QPW; ++qb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[qb][i] = 0.f;
 
+    if constexpr (CFG::SPLIT) {
+        if (w < 4) {
 #pragma unroll
-    for (int s0 = 0; s0 < NST - 1; ++s0) issue(s0);
+            for (int s0 = 0; s0 < CFG::NSTC - 1; ++s0) issue_corpus(s0);
+        } else if (SDAG_SCAN_QDMA) {
+#pragma unroll
+            for (int s0 = 0; s0 < CFG::NSTQ - 1; ++s0) issue_queries(s0);
+        } else {
+            static_assert(!CFG::SPLIT || CFG::NSTQ == 2, "query slabs through registers: one stage ahead");
+            load_queries(0);
+            store_queries(0);
+        }
+    } else {
+#pragma unroll
+        for (int s0 = 0; s0 < NST - 1; ++s0) {
+            issue_corpus(s0);
+            issue_queries(s0);
+        }
+    }
+    // ---- filtering a finished tile's scores into the per-query lists.  Register i of a tile's accumulator is corpus
+    // row 32 rg + (i & 3) + 8 (i >> 2) + 4 h of the tile, column r the query (of the block).  A round appends the
+    // survivors of four registers per query block (at most PUSH_MAX per list; one atomic per lane and block for all
+    // of its survivors); between rounds, behind a barrier, every wave compacts those of its lists that the next round
+    // could overflow.  (Riding the rounds on the barriers of the next tile's stages instead was measured slower.)
+    float* cs = reinterpret_cast<float*>(smem + OFF_CS);
+    int* ci = reinterpret_cast<int*>(smem + OFF_CI);
+    int* cnt = reinterpret_cast<int*>(smem + OFF_CNT);
+    auto push_round = [&](int round_base, const int64_t row_base) {
+#pragma unroll
+        for (int qb = 0; qb < QPW; ++qb) {
+            const int qi = (qg * QPW + qb) * 32 + r;  // the query's list
+            const float ts = reinterpret_cast<const float*>(smem + OFF_TS)[qi];
+            const int ti = reinterpret_cast<const int*>(smem + OFF_TI)[qi];
+            bool keep[4];
+            int n_keep = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = round_base + e;
+                const float sc = acc[qb][i];
+                const int64_t row = row_base + (i & 3) + 8 * (i >> 2);
+                keep[e] = qi < nq && row < N && sc == sc && better(sc, (int)row, ts, ti);
+                n_keep += keep[e] ? 1 : 0;
+            }
+            if (n_keep) {
+                int pos = atomicAdd(&cnt[qi], n_keep);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = round_base + e;
+                    if (keep[e]) {
+                        cs[qi * CAP + pos] = acc[qb][i];
+                        ci[qi * CAP + pos] = (int)(row_base + (i & 3) + 8 * (i >> 2));
+                        ++pos;
+                    }
+                }
+            }
+        }
+    };
+    auto compact_check = [&]() {  // the lengths of this wave's lists, one per lane
+        const int len = lane < LPW ? cnt[w * LPW + lane] : 0;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(len > CAP - PUSH_MAX);
+        while (todo) {
+            const int jj = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            compact_list<CFG>(smem, w * LPW + jj, k, lane);
+        }
+    };
+
     int tile = 0, kc = 0;
     for (int s = 0; s < S; ++s) {
         // stage s landed for this wave (the pieces of the newer stages may still fly), then for every wave
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(SCAN_WAIT) : "memory");
-        issue(s + NST - 1);
-        const unsigned char* sb = smem + (s % NST) * STAGE_BYTES;
+        if constexpr (CFG::SPLIT) {
+            if (w < 4) {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(CFG::WAIT_C) : "memory");
+                issue_corpus(s + CFG::NSTC - 1);
+            } else if (SDAG_SCAN_QDMA) {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(CFG::PPW_Q * (CFG::NSTQ - 2)) : "memory");
+                issue_queries(s + CFG::NSTQ - 1);
+            } else {
+                lds_barrier();  // (this wave's slab of stage s was written at the end of stage s - 1)
+                load_queries(s + 1);
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(CFG::WAIT_C) : "memory");
+            issue_corpus(s + NST - 1);
+            issue_queries(s + NST - 1);
+        }
+        const unsigned char* sbc = smem + (s % CFG::NSTC) * CFG::C_STRIDE;
+        const unsigned char* sbq = smem + CFG::Q_BASE + (s % CFG::NSTQ) * CFG::Q_STRIDE;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < ((SDAG_SCAN_EXP & 2) ? 0 : 4); ++m) {
             const int ch = ((2 * m + h) ^ swz) << 4;
             if constexpr (BF16) {
                 // 16-byte chunk 2 m + h of a row = dimensions 16 m + 8 h .. + 7 of the stage: the MFMA operand as it is
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sb + a_off + ch);
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(sb + b_off + ch);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sbc + a_off + ch);
+#pragma unroll
+                for (int qb = 0; qb < QPW; ++qb) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(sbq + b_off + qb * Q_STAGE + ch);
+                    acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[qb], 0, 0, 0);
+                }
             } else {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(sb + a_off + ch);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(sb + b_off + ch);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(sbc + a_off + ch);
                 // Lane half 0 holds dimensions 8m..8m+3, half 1 holds 8m+4..8m+7.  Swapping the upper half of
                 // register 0 with the lower half of register 1 (and 2 with 3) leaves register 0 = (8m, 8m+1),
                 // register 2 = (8m+2, 8m+3), register 1 = (8m+4, 8m+5), register 3 = (8m+6, 8m+7) across the
                 // two halves: the MFMA operand layout, in dimension order.
-                float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+                float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
                 swap_halves(a0, a1);
                 swap_halves(a2, a3);
-                swap_halves(b0, b1);
-                swap_halves(b2, b3);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc, 0, 0, 0);
-            }
-        }
-        if (++kc < nkc) continue;
-        kc = 0;
-
-        // ---- tile finished: accumulator register i is corpus row 32 w + (i & 3) + 8 (i >> 2) + 4 h of the
-        // tile, column r is the query.
-        const int64_t row_base = wg_row0 + (int64_t)tile * TR + w * 32 + 4 * h;
-        ++tile;
-        float* cs = reinterpret_cast<float*>(smem + OFF_CS);
-        int* ci = reinterpret_cast<int*>(smem + OFF_CI);
-        int* cnt = reinterpret_cast<int*>(smem + OFF_CNT);
 #pragma unroll
-        for (int round = 0; round < 4; ++round) {
-            const float ts = reinterpret_cast<const float*>(smem + OFF_TS)[r];
-            const int ti = reinterpret_cast<const int*>(smem + OFF_TI)[r];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = round * 4 + e;
-                const float sc = acc[i];
-                const int64_t row = row_base + (i & 3) + 8 * (i >> 2);
-                if (r < nq && row < N && sc == sc && better(sc, (int)row, ts, ti)) {
-                    const int pos = atomicAdd(&cnt[r], 1);
-                    cs[r * CAP + pos] = sc;
-                    ci[r * CAP + pos] = (int)row;
+                for (int qb = 0; qb < QPW; ++qb) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(sbq + b_off + qb * Q_STAGE + ch);
+                    float b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+                    swap_halves(b0, b1);
+                    swap_halves(b2, b3);
+                    acc[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[qb], 0, 0, 0);
+                    acc[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc[qb], 0, 0, 0);
+                    acc[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[qb], 0, 0, 0);
+                    acc[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc[qb], 0, 0, 0);
                 }
             }
-            lds_barrier();
-#pragma unroll 1
-            for (int jj = 0; jj < 8; ++jj) {
-                const int j = w * 8 + jj;
-                if (__builtin_amdgcn_readfirstlane(cnt[j]) > CAP - PUSH_MAX) compact_list(smem, j, k, lane);
+        }
+        if constexpr (CFG::SPLIT && !SDAG_SCAN_QDMA)
+            if (w >= 4) store_queries(s + 1);  // slab of stage s - 1: every wave passed this stage's barrier after reading it
+        if (++kc < nkc) continue;
+        kc = 0;
+        // ---- tile finished
+        const int64_t row_base = wg_row0 + (int64_t)tile * TR + rg * 32 + 4 * h;
+        ++tile;
+        if (!(SDAG_SCAN_EXP & 1)) {
+#pragma unroll
+            for (int round = 0; round < 4; ++round) {
+                push_round(round * 4, row_base);
+                lds_barrier();
+                compact_check();
+                lds_barrier();
             }
-            lds_barrier();
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int qb = 0; qb < QPW; ++qb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[qb][i] = 0.f;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
-    for (int jj = 0; jj < 8; ++jj) compact_list(smem, w * 8 + jj, k, lane);
+    for (int jj = 0; jj < LPW; ++jj) compact_list<CFG>(smem, w * LPW + jj, k, lane);
     lds_barrier();
     // ---- write this stripe's best k per query (fill: -FLT_MAX / -1)
-    for (int e = tid; e < QT * k; e += 256) {
+    for (int e = tid; e < QTW * k; e += 64 * NW) {
         const int j = e / k, t = e - j * k;
         const int n = reinterpret_cast<const int*>(smem + OFF_CNT)[j];
         const bool ok = j < nq && t < n;
-        const int64_t o = ((int64_t)blockIdx.x * QT + j) * k + t;
+        const int64_t o = ((int64_t)blockIdx.x * QTW + j) * k + t;
         part_s[o] = ok ? reinterpret_cast<const float*>(smem + OFF_CS)[j * CAP + t] : -FLT_MAX;
         part_i[o] = ok ? reinterpret_cast<const int*>(smem + OFF_CI)[j * CAP + t] : -1;
     }
@@ -376,7 +555,7 @@ inline int scan_keep(int k) {
 // clears the fallback flags of the call's query batches (n_flags of them).
 __global__ __launch_bounds__(256) void query_prepare_kernel(const float* __restrict__ Q, int d, const float* __restrict__ cmax,
                                                             unsigned short* __restrict__ Q16, float* __restrict__ eps,
-                                                            int* __restrict__ flags, int n_flags) {
+                                                            int* __restrict__ flags, int n_flags, int qtw) {
     __shared__ float red[256];
     const int q = blockIdx.x, tid = threadIdx.x;
     if (q == 0)
@@ -385,7 +564,11 @@ __global__ __launch_bounds__(256) void query_prepare_kernel(const float* __restr
     for (int j = tid; j < d; j += 256) {
         const float x = Q[(int64_t)q * d + j];
         ss = __builtin_fmaf(x, x, ss);
-        Q16[(int64_t)q * d + j] = __builtin_bit_cast(unsigned short, (__bf16)x);
+        // slab-major per pass of qtw queries: [pass][64-dimension stage][query of the pass][64]: the 128-byte pieces of
+        // one stage are contiguous, so every compute unit reading the same stage spreads over all L2 channels (rows of
+        // a row-major matrix are d * 2 bytes apart and land on a few)
+        const int64_t pass = q / qtw, jq = q % qtw;
+        Q16[((pass * (d / 64) + j / 64) * qtw + jq) * 64 + (j & 63)] = __builtin_bit_cast(unsigned short, (__bf16)x);
     }
     red[tid] = ss;
     __syncthreads();
@@ -439,16 +622,6 @@ constexpr int RS_CB = 32;     // candidates one block holds (and scores together
 constexpr int RS_DC = 256;    // dimensions of every candidate row in LDS at a time
 constexpr int RS_RW = RS_DC + 4;  // row stride of the LDS image in floats: 16 threads reading 16 bytes each hit 64 banks
 
-// Order-preserving map of a float's bits to an unsigned integer (larger float = larger key; -inf lowest of all values
-// that occur here), and back.
-__device__ __forceinline__ unsigned float_key(float x) {
-    const unsigned u = __float_as_uint(x);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key_float(unsigned key) {
-    return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
-}
-
 // The k-th largest of the 512 keys a wave holds (8 per lane), ties counted with multiplicity: the key is built from the
 // top bit down, keeping a bit whenever at least k keys reach the value it would give.  Wave-uniform, no LDS.
 __device__ __forceinline__ unsigned wave_kth_largest(const unsigned (&key)[8], int k) {
@@ -466,10 +639,11 @@ __device__ __forceinline__ unsigned wave_kth_largest(const unsigned (&key)[8], i
 // grid (RS_G, queries).  Every block finds the line (all stripes' maxima: 2 KB of loads), collects the candidates of
 // ITS stripes, scores them with the exact chain and writes its best k, sorted, as one partial list per (block, query)
 // in the layout the merge kernel reads; the merge of the RS_G lists gives the result.
+// q_stride: queries per stripe in the scan's lists and per block in the lists written here (the scan's pass width).
 __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ Q, const float* __restrict__ C, int d, int k, int ks,
                                                       const float* __restrict__ part_s, const int* __restrict__ part_i, int n_wg,
-                                                      const float* __restrict__ eps, float* __restrict__ blk_s, int* __restrict__ blk_i,
-                                                      int* __restrict__ flag) {
+                                                      int q_stride, const float* __restrict__ eps, float* __restrict__ blk_s,
+                                                      int* __restrict__ blk_i, int* __restrict__ flag) {
     __shared__ __attribute__((aligned(16))) float rows[RS_CB * RS_RW];
     __shared__ __attribute__((aligned(16))) float qs[RS_DC];
     __shared__ int cand[RS_CB];
@@ -484,13 +658,14 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < MAX_WG / 64; ++i) {
         const int p = 64 * i + lane;
-        const int64_t src = ((int64_t)(p < n_wg ? p : 0) * QT + q) * ks;
+        const int64_t src = ((int64_t)(p < n_wg ? p : 0) * q_stride + q) * ks;
         const int id0 = part_i[src];   // both words requested together: one round trip
         const float s0 = part_s[src];
         key[i] = float_key(p < n_wg && id0 >= 0 ? s0 : -INFINITY);
     }
     const float lb = key_float(wave_kth_largest(key, k));
     const float thr = lb == -INFINITY ? -INFINITY : lb - 2.0f * eps[q];
+    if (thr != thr && tid == 0) atomicOr(flag, 1);  // a line that is not a number selects nothing: let the exact scan answer
     const unsigned thr_key = float_key(thr);
     __syncthreads();  // the counters are zero
     // ---- candidates: this block's stripes whose maximum reaches the line, then every (stripe, place) pair of those at
@@ -506,7 +681,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
     const int npairs = nqual_s * ks;
     for (int e = tid; e < npairs; e += 256) {
         const int p = qual[e / ks], t = e - (e / ks) * ks;
-        const int64_t src = ((int64_t)p * QT + q) * ks + t;
+        const int64_t src = ((int64_t)p * q_stride + q) * ks + t;
         const int id = part_i[src];
         const float sc = part_s[src];
         if (id < 0 || !(sc >= thr)) continue;
@@ -593,7 +768,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
     __syncthreads();
     // ---- this block's best k, sorted, as partial list g of query q (equal entries - fills - ordered by position, so
     // every rank is taken exactly once)
-    const int64_t ob = ((int64_t)g * QT + q) * k;
+    const int64_t ob = ((int64_t)g * q_stride + q) * k;
     for (int c = tid; c < n; c += 256) {
         const float sc = ex[c];
         const int ic = cand[c];
@@ -662,10 +837,21 @@ __global__ __launch_bounds__(256) void centroid_batch_kernel(const float* __rest
     }
 }
 
+// Query blocks per pass for a search of nq queries keeping ks entries per stripe: as many as the queries fill, the
+// widest only while its shorter lists hold ks entries.
+inline int pass_blocks(int nq, int ks) {
+    if (nq <= QT) return 1;
+    if (nq <= 2 * QT || ks > WIDE_KS) return 2;
+    return MAX_NQB;
+}
+
 struct ScanPlan { int n_wg; int rows_per_wg; };
-inline ScanPlan plan_scan(int64_t N) {
+// Stripes of a scan with nqb query blocks per pass: what the chip holds at once (the narrow scan runs two workgroups per
+// compute unit, the wide ones one of twice the waves).
+inline ScanPlan plan_scan(int64_t N, int nqb = 1) {
+    const int max_wg = nqb == 1 ? SCAN_WG : 256;
     int64_t tiles = (N + TR - 1) / TR;
-    int64_t n_wg = tiles < SCAN_WG ? tiles : SCAN_WG;
+    int64_t n_wg = tiles < max_wg ? tiles : max_wg;
     if (n_wg < 1) n_wg = 1;
     int64_t tiles_per = (tiles + n_wg - 1) / n_wg;
     if (tiles_per < 1) tiles_per = 1;
@@ -679,11 +865,39 @@ inline ScanPlan plan_scan(int64_t N) {
 
 using namespace sdag;
 
+namespace {
+template <bool BF16, int NQB, int NW>
+int launch_scan_cfg(int n_wg, hipStream_t st, const void* Q, int nqt, const void* C, int64_t N, int d, int k, int rows_per_wg,
+                    float* part_s, int* part_i, const int* run_flag, bool slab_major) {
+    using CFG = ScanCfg<NQB, NW>;
+    const int es = BF16 ? 2 : 4;
+    const int q_row_bytes = slab_major ? 128 : d * es, q_kc_bytes = slab_major ? 128 * CFG::QTW : 128;
+    SDAG_HIP_CHECK(hipFuncSetAttribute((const void*)dense_scan<BF16, NQB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS));
+    hipLaunchKernelGGL((dense_scan<BF16, NQB, NW>), dim3(n_wg), dim3(64 * NW), CFG::LDS, st, Q, nqt, C, N, d, k, rows_per_wg, part_s,
+                       part_i, run_flag, q_row_bytes, q_kc_bytes);
+    SDAG_HIP_CHECK(hipGetLastError());
+    return SDAG_OK;
+}
+
+// One pass of the scan over the corpus for nqt <= 32 nqb queries.
+template <bool BF16>
+int launch_scan(int nqb, int n_wg, hipStream_t st, const void* Q, int nqt, const void* C, int64_t N, int d, int k, int rows_per_wg,
+                float* part_s, int* part_i, const int* run_flag, bool slab_major) {
+    switch (nqb) {
+        case 1: return launch_scan_cfg<BF16, 1, 4>(n_wg, st, Q, nqt, C, N, d, k, rows_per_wg, part_s, part_i, run_flag, slab_major);
+        case 2: return launch_scan_cfg<BF16, 2, 8>(n_wg, st, Q, nqt, C, N, d, k, rows_per_wg, part_s, part_i, run_flag, slab_major);
+        case 4: return launch_scan_cfg<BF16, 4, 8>(n_wg, st, Q, nqt, C, N, d, k, rows_per_wg, part_s, part_i, run_flag, slab_major);
+    }
+    return fail(SDAG_ERR_ARG, "bad pass width");
+}
+}  // namespace
+
 extern "C" int64_t sdag_dense_workspace_bytes(int nq, int64_t N, int d, int k) {
-    (void)nq; (void)d;
-    if (k <= 0 || k > MAX_K || N < 0) return -1;
-    const ScanPlan pl = plan_scan(N);
-    return ((int64_t)pl.n_wg * QT * k * 8 + 255) & ~255ll;
+    (void)d;
+    if (k <= 0 || k > MAX_K || N < 0 || nq < 0) return -1;
+    const int nqb = pass_blocks(nq, k);
+    const ScanPlan pl = plan_scan(N, nqb);
+    return ((int64_t)pl.n_wg * QT * nqb * k * 8 + 255) & ~255ll;
 }
 
 extern "C" int sdag_dense_topk(const float* Q, int nq, const float* C, int64_t N, int d, int k,
@@ -697,21 +911,20 @@ extern "C" int sdag_dense_topk(const float* Q, int nq, const float* C, int64_t N
     if (!Q || !out_s || !out_i || (N > 0 && !C)) return fail(SDAG_ERR_ARG, "NULL pointer");
     if (((uintptr_t)Q | (uintptr_t)C) & 15) return fail(SDAG_ERR_ARG, "Q and C must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    const ScanPlan pl = plan_scan(N);
+    const int nqb = pass_blocks(nq, k), qtw = QT * nqb;
+    const ScanPlan pl = plan_scan(N, nqb);
     const int64_t need = sdag_dense_workspace_bytes(nq, N, d, k);
     if (!workspace || workspace_bytes < need) return fail(SDAG_ERR_CAPACITY, "workspace needs %lld bytes", (long long)need);
     float* part_s = (float*)workspace;
-    int* part_i = (int*)(part_s + (int64_t)pl.n_wg * QT * k);
+    int* part_i = (int*)(part_s + (int64_t)pl.n_wg * qtw * k);
     if ((( (int64_t)pl.n_wg * k + 63) / 64) * k > MRG_A) return fail(SDAG_ERR_ARG, "too many partial lists for the merge");
-    for (int q0 = 0; q0 < nq; q0 += QT) {
-        const int nqt = nq - q0 < QT ? nq - q0 : QT;
-        if (N > 0) {
-            SDAG_HIP_CHECK(hipFuncSetAttribute((const void*)dense_scan<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS));
-            hipLaunchKernelGGL(dense_scan<false>, dim3(pl.n_wg), dim3(256), SCAN_LDS, st, (const void*)(Q + (int64_t)q0 * d), nqt,
-                               (const void*)C, N, d, k, pl.rows_per_wg, part_s, part_i, (const int*)nullptr);
-            SDAG_HIP_CHECK(hipGetLastError());
-        }
-        hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, part_s, part_i, N > 0 ? pl.n_wg : 0, nqt, QT,
+    for (int q0 = 0; q0 < nq; q0 += qtw) {
+        const int nqt = nq - q0 < qtw ? nq - q0 : qtw;
+        if (N > 0)
+            if (int rc = launch_scan<false>(nqb, pl.n_wg, st, (const void*)(Q + (int64_t)q0 * d), nqt, (const void*)C, N, d, k,
+                                            pl.rows_per_wg, part_s, part_i, (const int*)nullptr, false))
+                return rc;
+        hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, part_s, part_i, N > 0 ? pl.n_wg : 0, nqt, qtw,
                            k, id_base, out_s + (int64_t)q0 * k, out_i + (int64_t)q0 * k, (const int*)nullptr);
         SDAG_HIP_CHECK(hipGetLastError());
     }
@@ -734,21 +947,23 @@ extern "C" int sdag_corpus_to_bf16(const float* C, int64_t N, int d, void* C16, 
 }
 
 namespace {
-struct Ws2 { int64_t part_s, part_i, flag, eps, q16, exact, rs, total; int n_flags; };
+struct Ws2 { int64_t part_s, part_i, flag, eps, q16, exact, rs, total; int n_flags, nqb; };
 Ws2 plan_ws2(int nq, int64_t N, int d, int k) {
-    const ScanPlan pl = plan_scan(N);
     const int ks = scan_keep(k);
     Ws2 w;
+    w.nqb = pass_blocks(nq, ks);
+    const int qtw = QT * w.nqb;
+    const ScanPlan pl = plan_scan(N, w.nqb);
     int64_t off = 0;
     auto take = [&](int64_t bytes) { const int64_t o = off; off += (bytes + 255) & ~255ll; return o; };
-    w.part_s = take((int64_t)pl.n_wg * QT * ks * 4);
-    w.part_i = take((int64_t)pl.n_wg * QT * ks * 4);
-    w.n_flags = (nq + QT - 1) / QT;  // one fallback flag per batch of QT queries
+    w.part_s = take((int64_t)pl.n_wg * qtw * ks * 4);
+    w.part_i = take((int64_t)pl.n_wg * qtw * ks * 4);
+    w.n_flags = (nq + qtw - 1) / qtw;  // one fallback flag per pass over the corpus
     w.flag = take((int64_t)(w.n_flags > 0 ? w.n_flags : 1) * 4);
     w.eps = take((int64_t)nq * 4);
-    w.q16 = take((int64_t)nq * d * 2);
-    w.exact = take((int64_t)pl.n_wg * QT * k * 8);
-    w.rs = take((int64_t)RS_G * QT * k * 8);  // the rescoring blocks' partial lists
+    w.q16 = take((int64_t)w.n_flags * qtw * d * 2);  // whole passes (slab-major)
+    w.exact = take((int64_t)pl.n_wg * qtw * k * 8);
+    w.rs = take((int64_t)RS_G * qtw * k * 8);  // the rescoring blocks' partial lists
     w.total = off;
     return w;
 }
@@ -762,7 +977,7 @@ extern "C" int64_t sdag_dense_topk2_workspace_bytes(int nq, int64_t N, int d, in
 extern "C" int64_t sdag_dense_topk2_flag_offset(int nq, int64_t N, int d, int k) {
     if (k <= 0 || k > MAX_K || N < 0 || nq < 0 || d <= 0) return -1;
     const Ws2 w = plan_ws2(nq, N, d, k);
-    return w.flag + (int64_t)(w.n_flags > 0 ? w.n_flags - 1 : 0) * 4;  // the last batch's flag
+    return w.flag + (int64_t)(w.n_flags > 0 ? w.n_flags - 1 : 0) * 4;  // the last pass's flag
 }
 
 extern "C" int sdag_dense_topk2(const float* Q, int nq, const float* C, const void* C16, const float* max_row_norm, int64_t N,
@@ -776,8 +991,9 @@ extern "C" int sdag_dense_topk2(const float* Q, int nq, const float* C, const vo
     if (!Q || !out_s || !out_i || !max_row_norm || (N > 0 && (!C || !C16))) return fail(SDAG_ERR_ARG, "NULL pointer");
     if (((uintptr_t)Q | (uintptr_t)C | (uintptr_t)C16) & 15) return fail(SDAG_ERR_ARG, "Q, C and C16 must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    const ScanPlan pl = plan_scan(N);
     const Ws2 w = plan_ws2(nq, N, d, k);
+    const int nqb = w.nqb, qtw = QT * nqb;
+    const ScanPlan pl = plan_scan(N, nqb);
     if (!workspace || workspace_bytes < w.total) return fail(SDAG_ERR_CAPACITY, "workspace needs %lld bytes", (long long)w.total);
     unsigned char* ws = (unsigned char*)workspace;
     float* part_s = (float*)(ws + w.part_s);
@@ -786,37 +1002,34 @@ extern "C" int sdag_dense_topk2(const float* Q, int nq, const float* C, const vo
     float* eps = (float*)(ws + w.eps);
     unsigned short* q16 = (unsigned short*)(ws + w.q16);
     float* ex_s = (float*)(ws + w.exact);
-    int* ex_i = (int*)(ex_s + (int64_t)pl.n_wg * QT * k);
+    int* ex_i = (int*)(ex_s + (int64_t)pl.n_wg * qtw * k);
     float* rs_s = (float*)(ws + w.rs);
-    int* rs_i = (int*)(rs_s + (int64_t)RS_G * QT * k);
+    int* rs_i = (int*)(rs_s + (int64_t)RS_G * qtw * k);
     const int ks = scan_keep(k);
     if ((((int64_t)pl.n_wg * k + 63) / 64) * k > MRG_A) return fail(SDAG_ERR_ARG, "too many partial lists for the merge");
-    hipLaunchKernelGGL(query_prepare_kernel, dim3(nq), dim3(256), 0, st, Q, d, max_row_norm, q16, eps, flags, w.n_flags);
+    hipLaunchKernelGGL(query_prepare_kernel, dim3(nq), dim3(256), 0, st, Q, d, max_row_norm, q16, eps, flags, w.n_flags, qtw);
     SDAG_HIP_CHECK(hipGetLastError());
-    SDAG_HIP_CHECK(hipFuncSetAttribute((const void*)dense_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS));
-    SDAG_HIP_CHECK(hipFuncSetAttribute((const void*)dense_scan<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS));
-    for (int q0 = 0; q0 < nq; q0 += QT) {
-        const int nqt = nq - q0 < QT ? nq - q0 : QT;
+    for (int q0 = 0; q0 < nq; q0 += qtw) {
+        const int nqt = nq - q0 < qtw ? nq - q0 : qtw;
         float* os = out_s + (int64_t)q0 * k;
         int64_t* oi = out_i + (int64_t)q0 * k;
-        int* flag = flags + q0 / QT;
-        if (N > 0) {
-            hipLaunchKernelGGL(dense_scan<true>, dim3(pl.n_wg), dim3(256), SCAN_LDS, st, (const void*)(q16 + (int64_t)q0 * d), nqt, C16,
-                               N, d, ks, pl.rows_per_wg, part_s, part_i, (const int*)nullptr);
-            SDAG_HIP_CHECK(hipGetLastError());
-        }
+        int* flag = flags + q0 / qtw;
+        if (N > 0)
+            if (int rc = launch_scan<true>(nqb, pl.n_wg, st, (const void*)(q16 + (int64_t)q0 * d), nqt, C16, N, d, ks, pl.rows_per_wg,
+                                           part_s, part_i, (const int*)nullptr, true))
+                return rc;
         hipLaunchKernelGGL(rescore_kernel, dim3(RS_G, nqt), dim3(256), 0, st, Q + (int64_t)q0 * d, C, d, k, ks, part_s, part_i,
-                           N > 0 ? pl.n_wg : 0, eps + q0, rs_s, rs_i, flag);
+                           N > 0 ? pl.n_wg : 0, qtw, eps + q0, rs_s, rs_i, flag);
         SDAG_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, rs_s, rs_i, RS_G, nqt, QT, k, id_base, os, oi,
+        hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, rs_s, rs_i, RS_G, nqt, qtw, k, id_base, os, oi,
                            (const int*)nullptr);
         SDAG_HIP_CHECK(hipGetLastError());
-        if (N > 0) {
-            // only when the rescoring kernel could not vouch for its candidate set: the exact scan of the batch
-            hipLaunchKernelGGL(dense_scan<false>, dim3(pl.n_wg), dim3(256), SCAN_LDS, st, (const void*)(Q + (int64_t)q0 * d), nqt,
-                               (const void*)C, N, d, k, pl.rows_per_wg, ex_s, ex_i, (const int*)flag);
-            SDAG_HIP_CHECK(hipGetLastError());
-            hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, ex_s, ex_i, pl.n_wg, nqt, QT, k, id_base, os,
+        if (N > 0 && !SDAG_SCAN_EXP) {
+            // only when the rescoring kernel could not vouch for its candidate set: the exact scan of the pass
+            if (int rc = launch_scan<false>(nqb, pl.n_wg, st, (const void*)(Q + (int64_t)q0 * d), nqt, (const void*)C, N, d, k,
+                                            pl.rows_per_wg, ex_s, ex_i, (const int*)flag, false))
+                return rc;
+            hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, ex_s, ex_i, pl.n_wg, nqt, qtw, k, id_base, os,
                                oi, (const int*)flag);
             SDAG_HIP_CHECK(hipGetLastError());
         }

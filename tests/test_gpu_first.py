@@ -100,6 +100,37 @@ def test_dense_topk_bit_exact(N, d, nq, k):
             assert not idx.last_search_fell_back()   # a large ordinary corpus is answered from the candidates
 
 
+@pytest.mark.parametrize("N,d,nq,k", [(30000, 128, 33, 10), (50000, 256, 100, 10), (20000, 64, 256, 5), (9000, 128, 1024, 10),
+                                      (30000, 128, 100, 20), (5000, 64, 300, 32), (70000, 1024, 128, 13), (3, 64, 130, 4)])
+def test_dense_topk_more_than_32_queries_per_pass(N, d, nq, k):
+    """The reference hands the whole query matrix to one index.search (dense.py:82-84).  Beyond 32 queries the scan
+    multiplies every staged corpus tile against 64 or 128 queries (128 only while the stripe lists hold <= 16
+    entries, else 64): ids and score bits equal to the oracle for both the two-stage and the exact search, with exact
+    ties, query counts that do not fill the last pass, and a corpus smaller than k."""
+    import sdag_amd
+    from oracle import dense_ref
+
+    rng = np.random.default_rng(N + nq)
+    C = rng.standard_normal((N, d), dtype=np.float32)
+    C /= np.linalg.norm(C, axis=1, keepdims=True)
+    Q = rng.standard_normal((nq, d), dtype=np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    if N >= 1000:
+        C[N // 2] = C[N // 3]
+        C[N - 1] = C[0]
+        Q[nq - 1] = C[N // 3]       # the tied rows lead the last query's list
+    rs, ri = dense_ref.dense_topk(Q, C, k, id_base=11)
+    for two_stage in (True, False):
+        idx = sdag_amd.FlatIPIndex(d, device=_dev(), id_base=11, two_stage=two_stage)
+        idx.add(C)
+        s, i = idx.search(Q, k)
+        assert np.array_equal(i, ri), (two_stage, np.argwhere(i != ri)[:5])
+        assert np.array_equal(s.view(np.uint32), rs.view(np.uint32)), two_stage
+        # the same queries 32 at a time (the narrow scan) give the same bits
+        s32 = np.concatenate([idx.search(Q[a:a + 32], k)[0] for a in range(0, nq, 32)])
+        assert np.array_equal(s32.view(np.uint32), s.view(np.uint32))
+
+
 def test_two_stage_search_when_candidates_abound():
     """Corpora built against the candidate scan: hundreds of rows within rounding distance of the best score (more
     candidates than the rescoring kernel holds, and whole stripes full of them), exact duplicates, a corpus smaller
