@@ -251,7 +251,7 @@ class DescriptorPipeline:
 
     def _descs(self):
         c = self.cfg
-        return [self.sdag.from_spans(L, c["sys_len"], spans, qa, nbr, max_items_per_unit=64) for spans, qa, L, nbr in self.prompts]
+        return self.sdag.from_spans_many([(L, c["sys_len"], spans, qa, nbr) for spans, qa, L, nbr in self.prompts], max_items_per_unit=64)
 
     def build(self):
         """-> (batch table bound to its device copy, event after which the device copy is complete, slot)."""

@@ -86,7 +86,8 @@ constexpr int DEFAULT_STREAMS = 64;
 // ---- batch table (int32 words): several sequences, each with its own descriptor, in one launch ------------
 // header | desc_off[B] | slot_base[B] | merge {sequence, split index} | uniform {sequence, row} | stream offsets |
 // steps (as in a descriptor, with S_B the sequence, S_SLOT global and S_MOFF relative to the table) | the
-// descriptors themselves (each at a multiple of 16 words).  Units are dealt to the streams in sequence-major
+// descriptors themselves (each at a multiple of 16 words, copied up to their own step records, which a batch
+// table never uses: their headers still describe the full descriptor).  Units are dealt to the streams in sequence-major
 // order, longest first inside a sequence, so the workgroups running at any time read the K/V of few sequences.
 constexpr int32_t BATCH_MAGIC = 0x54424453;  // "SDBT"
 enum : int {

@@ -233,7 +233,8 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
     // ---- Q fragments: B operand of S^T = K Q^T; lane (r, h) holds Q[row][16 ks + 8 h .. +7].
     bf16x8 qf[8];
     // Buffer loads: one descriptor per unit over this head's slice of sequence b (wave-uniform), a 32-bit offset per
-    // lane (its row, its half of every 32-byte piece) and the piece as the instruction's immediate.
+    // lane (its row, its half of every 32-byte piece) and the piece as the instruction's immediate.  Every instruction
+    // gathers 32 bytes from each of 32 rows: used once per workgroup, for its first unit.
     auto load_q = [&](int b, int row0, int L) {
         const unsigned qrow = (unsigned)p.q_sl * 2u;
         const auto qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.q + (int64_t)b * p.q_sb + (int64_t)hq * p.q_sh), 0,
@@ -242,7 +243,20 @@ __global__ __launch_bounds__(256, 2) void sdag_attn_main(const AttnParams p) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(qrs, qoff + 32u * ks, 0, 0));
     };
-
+    // The rows of every later unit arrive as WHOLE rows (lane -> row 4 j + (lane >> 4), 16-byte chunk lane & 15: four
+    // 256-byte rows per instruction instead of 32 pieces of 32 bytes), raw in the registers of the fragments, which
+    // the unit that ends no longer needs; rows past L read as zeros (the descriptor ends with the sequence's last
+    // row).  q_fragments() then turns them into the fragments through the wave's own pieces of the tile buffer that
+    // was just consumed (the image O is staged in at a unit's end): eight 16-byte writes, eight reads, no barrier.
+    auto load_q_rows = [&](int b, int row0, int L) {
+        const unsigned qrow = (unsigned)p.q_sl * 2u;
+        const auto qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.q + (int64_t)b * p.q_sb + (int64_t)hq * p.q_sh), 0,
+                                                           (int)((unsigned)(L - 1) * qrow + (unsigned)(D * 2)), 0x00020000);
+        const unsigned qoff = (unsigned)(row0 + (lane >> 4)) * qrow + 16u * (unsigned)(lane & 15);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            qf[j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(qrs, qoff + (unsigned)(4 * j) * qrow, 0, 0));
+    };
     // ---- staging geometry: thread covers chunk (tid & 15) of rows (tid >> 4) + 16 i, i = 0..3.
     const int st_row = tid >> 4, st_ch = tid & 15;
     const int st_off = tile_off(st_row, st_ch);  // + 16 * 256 * i for the other rows (swizzle term unchanged)

@@ -28,13 +28,15 @@ constexpr int RB = SDAG_ROW_BLOCK;
 constexpr int KT = SDAG_KV_TILE;
 static_assert(RB == 32 && KT == 64, "descriptor masks are 32 rows of one 64-bit word");
 
-inline void set_range(uint64_t* row_bits, int a, int b) {  // columns [a, b), b > a
+// columns [a, b), b > a, of one bit row; `touched[t]` is set for every 64-bit word t written
+inline void set_range(uint64_t* row_bits, uint8_t* touched, int a, int b) {
     const int t0 = a >> 6, t1 = (b - 1) >> 6;
     for (int t = t0; t <= t1; ++t) {
         const int lo = t == t0 ? (a & 63) : 0;
         const int hi = t == t1 ? ((b - 1) & 63) : 63;  // inclusive
         const uint64_t m = (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1)) & ~((1ull << lo) - 1);
         row_bits[t] |= m;
+        touched[t] = 1;
     }
 }
 
@@ -120,24 +122,39 @@ void build_schedule(const std::vector<SchedUnit>& units, int n_streams, int32_t*
     stream_off[n_streams] = (int32_t)n;
 }
 
-// 32 rows x 64 bits regrouped per accumulator register of the attention kernel (see common.h).
-void lane_mask_image(const uint64_t* rows, uint64_t* out) {
-    for (int kb = 0; kb < 2; ++kb)
-        for (int i = 0; i < 16; ++i) {
-            uint64_t w = 0;
-            for (int h = 0; h < 2; ++h) {
-                const int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                for (int r = 0; r < 32; ++r) w |= ((rows[r] >> key) & 1ull) << (r + 32 * h);
-            }
-            out[16 * kb + i] = w;
+// In-place transpose of a 32 x 32 bit matrix: afterwards bit r of a[c] is what bit c of a[r] was (five rounds of
+// block swaps, 16 x 16 down to 1 x 1).
+inline void transpose32(uint32_t* a) {
+    uint32_t m = 0x0000ffffu;
+    for (int j = 16; j != 0; j >>= 1, m ^= m << j)
+        for (int k = 0; k < 32; k = (k + j + 1) & ~j) {
+            const uint32_t t = ((a[k] >> j) ^ a[k + j]) & m;
+            a[k] ^= t << j;
+            a[k + j] ^= t;
         }
+}
+
+// 32 rows x 64 bits regrouped per accumulator register of the attention kernel (see common.h): word 16 kb + i holds,
+// for h = 0, 1, bit (r + 32 h) = row r's bit of key 32 kb + (i & 3) + 8 (i >> 2) + 4 h -- the columns of the two
+// 32 x 32 halves of the mask, paired.
+void lane_mask_image(const uint64_t* rows, uint64_t* out) {
+    for (int kb = 0; kb < 2; ++kb) {
+        uint32_t t[32];
+        for (int r = 0; r < 32; ++r) t[r] = (uint32_t)(rows[r] >> (32 * kb));
+        transpose32(t);  // t[key] bit r
+        for (int i = 0; i < 16; ++i) {
+            const int key = (i & 3) + 8 * (i >> 2);
+            out[16 * kb + i] = (uint64_t)t[key] | ((uint64_t)t[key + 4] << 32);
+        }
+    }
 }
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
-// fill(row0, rows, bits): the allowed keys of rows row0 .. row0 + rows - 1 as bit rows of nw = ceil(L / 64) words,
-// bits[r * nw + w], zeroed by the caller.
-using FillFn = std::function<void(int, int, uint64_t*)>;
+// fill(row0, rows, bits, touched): the allowed keys of rows row0 .. row0 + rows - 1 as bit rows of nw = ceil(L / 64)
+// words, bits[r * nw + w], zeroed by the caller; touched[w] = 1 for every word index w it wrote in any row (a row of a
+// document sees a few dozen of a long prompt's words: everything after the fill walks those words only).
+using FillFn = std::function<void(int, int, uint64_t*, uint8_t*)>;
 
 // 64 bits of a bit row starting at bit `pos` (bits at and beyond 64 * nw read as zero).
 inline uint64_t window(const uint64_t* row, int nw, int pos) {
@@ -166,7 +183,9 @@ int emit(int L, std::vector<int> cuts, const FillFn& fill, int max_items_per_uni
     const int nrb = (int)rb_row0.size();
     auto rb_rows = [&](int rb) { return (rb + 1 < nrb ? rb_row0[rb + 1] : L) - rb_row0[rb]; };
 
-    std::vector<uint64_t> bits((size_t)RB * std::max(nw, 1)), uni_cols((size_t)std::max(nw, 1));
+    std::vector<uint64_t> bits((size_t)RB * std::max(nw, 1), 0ull), uni_cols((size_t)std::max(nw, 1), 0ull);
+    std::vector<uint8_t> touched((size_t)std::max(nw, 1), 0);
+    std::vector<int32_t> tw;               // the touched word indices of the current block
     std::vector<int32_t> items;            // {key0, mask}
     std::vector<int32_t> rb_item_begin(nrb + 1, 0);
     std::vector<uint64_t> masks;           // 32 words per mask
@@ -176,14 +195,17 @@ int emit(int L, std::vector<int> cuts, const FillFn& fill, int max_items_per_uni
 
     for (int rb = 0; rb < nrb; ++rb) {
         const int row0 = rb_row0[rb], rows = rb_rows(rb);
-        std::fill(bits.begin(), bits.end(), 0ull);
-        fill(row0, rows, bits.data());
-        std::fill(uni_cols.begin(), uni_cols.end(), 0ull);
+        // (bits, uni_cols and touched are all zero here: the previous block cleared what it had written)
+        fill(row0, rows, bits.data(), touched.data());
+        tw.clear();
+        for (int t = 0; t < nw; ++t)
+            if (touched[t]) tw.push_back(t);
         uint32_t skip = rows < RB ? ~0u << rows : 0u;
         for (int r = 0; r < rows; ++r) {
             uint64_t any = 0;
-            for (int t = 0; t < nw; ++t) {
-                const uint64_t w = bits[(size_t)r * nw + t];
+            const uint64_t* row = bits.data() + (size_t)r * nw;
+            for (int32_t t : tw) {
+                const uint64_t w = row[t];
                 any |= w;
                 uni_cols[t] |= w;
                 pairs += __builtin_popcountll(w);
@@ -214,6 +236,11 @@ int emit(int L, std::vector<int> cuts, const FillFn& fill, int max_items_per_uni
             c = key0 + KT;
         }
         rb_item_begin[rb + 1] = (int32_t)(items.size() / 2);
+        for (int32_t t : tw) {  // leave the buffers zero for the next block
+            for (int r = 0; r < rows; ++r) bits[(size_t)r * nw + t] = 0ull;
+            uni_cols[t] = 0ull;
+            touched[t] = 0;
+        }
     }
 
     const int n_items = (int)(items.size() / 2);
@@ -342,21 +369,21 @@ extern "C" int sdag_desc_build(int L, int sys_user_len, int n_docs, const int32_
         if (n_docs > 0 && nbr_off[n_docs] > 0 && !nbr_idx) return fail(SDAG_ERR_ARG, "nbr_idx is NULL");
     }
     const int nkt = (L + SDAG_KV_TILE - 1) / SDAG_KV_TILE;
-    auto fill = [&](int r0, int rows, uint64_t* bits) {
+    auto fill = [&](int r0, int rows, uint64_t* bits, uint8_t* touched) {
         for (int i = r0; i < r0 + rows; ++i) {
             uint64_t* row = bits + (size_t)(i - r0) * nkt;
-            if (i < sys_user_len || i >= qa_start) set_range(row, 0, i + 1);  // SDAG.py:107-108, 124-125
+            if (i < sys_user_len || i >= qa_start) set_range(row, touched, 0, i + 1);  // SDAG.py:107-108, 124-125
             for (int d = 0; d < n_docs; ++d) {
                 const int s = spans[2 * d], e = spans[2 * d + 1];
                 if (i < s || i >= e) continue;
-                if (sys_user_len > 0) set_range(row, 0, sys_user_len);  // SDAG.py:115
-                set_range(row, s, i + 1);                               // SDAG.py:116
+                if (sys_user_len > 0) set_range(row, touched, 0, sys_user_len);  // SDAG.py:115
+                set_range(row, touched, s, i + 1);                               // SDAG.py:116
                 if (nbr_off) {
                     for (int t = nbr_off[d]; t < nbr_off[d + 1]; ++t) {  // SDAG.py:118-122
                         const int nb = nbr_idx[t];
                         if (nb < 0 || nb >= n_docs) continue;
                         const int ns = spans[2 * nb], ne = spans[2 * nb + 1];
-                        if (ne > ns) set_range(row, ns, ne);
+                        if (ne > ns) set_range(row, touched, ns, ne);
                     }
                 }
             }
@@ -375,12 +402,15 @@ extern "C" int sdag_desc_from_dense(const uint8_t* mask, int L, int max_items_pe
                                     int64_t cap_words, int64_t* n_words) {
     if (L < 0 || (L > 0 && !mask)) return fail(SDAG_ERR_ARG, "bad dense mask");
     const int nkt = (L + SDAG_KV_TILE - 1) / SDAG_KV_TILE;
-    auto fill = [&](int r0, int rows, uint64_t* bits) {
+    auto fill = [&](int r0, int rows, uint64_t* bits, uint8_t* touched) {
         for (int i = r0; i < r0 + rows; ++i) {
             const uint8_t* src = mask + (size_t)i * L;
             uint64_t* row = bits + (size_t)(i - r0) * nkt;
             for (int j = 0; j < L; ++j)
-                if (src[j]) row[j >> 6] |= 1ull << (j & 63);
+                if (src[j]) {
+                    row[j >> 6] |= 1ull << (j & 63);
+                    touched[j >> 6] = 1;
+                }
         }
     };
     return emit(L, {}, fill, max_items_per_unit, n_streams, out, cap_words, n_words);
@@ -436,7 +466,7 @@ extern "C" int sdag_batch_build(const int32_t* const* descs, int B, int n_stream
             uniq.push_back(descs[b]);
             off = align_up(off, 16);
             desc_off[b] = (int32_t)off;
-            off += descs[b][H_TOTAL_WORDS];
+            off += descs[b][H_OFF_STEPS];  // without its own step records (the last part): the batch has its own
         } else {
             for (int c = 0; c < b; ++c)
                 if (descs[c] == descs[b]) { desc_off[b] = desc_off[c]; break; }
@@ -446,7 +476,19 @@ extern "C" int sdag_batch_build(const int32_t* const* descs, int B, int n_stream
     if (n_words) *n_words = total;
     if (total > 0x7fffffff || n_slots > 0x7fffffff) return fail(SDAG_ERR_ARG, "batch table too large");
     if (!out || cap_words < total) return fail(SDAG_ERR_CAPACITY, "batch table needs %lld words, buffer has %lld", (long long)total, (long long)cap_words);
-    std::memset(out, 0, sizeof(int32_t) * (size_t)total);
+    // Zero what nothing below writes: the head of the table up to the step records (every word of those is written by
+    // build_schedule) and the few alignment words around the sequences' copies -- not the megabytes in between.
+    std::memset(out, 0, sizeof(int32_t) * (size_t)off_steps);
+    {
+        int64_t end = off_steps + n_steps * STEP_WORDS;  // end of what has been accounted for so far
+        for (const int32_t* u : uniq) {
+            int b = 0;
+            while (descs[b] != u) ++b;
+            for (int64_t w = end; w < desc_off[b]; ++w) out[w] = 0;
+            end = (int64_t)desc_off[b] + u[H_OFF_STEPS];
+        }
+        for (int64_t w = end; w < total; ++w) out[w] = 0;
+    }
     out[BT_MAGIC] = BATCH_MAGIC;
     out[BT_VERSION] = BATCH_VERSION;
     out[BT_B] = B;
@@ -470,7 +512,9 @@ extern "C" int sdag_batch_build(const int32_t* const* descs, int B, int n_stream
     }
     if (!merge.empty()) std::memcpy(out + off_merge, merge.data(), sizeof(int32_t) * merge.size());
     if (!uniform.empty()) std::memcpy(out + off_uniform, uniform.data(), sizeof(int32_t) * uniform.size());
-    for (int b = 0; b < B; ++b) std::memcpy(out + desc_off[b], descs[b], sizeof(int32_t) * (size_t)descs[b][H_TOTAL_WORDS]);
+    // (a sequence's copy keeps its header as it is: H_TOTAL_WORDS and H_OFF_STEPS still describe the full descriptor,
+    // whose step records are not part of the copy and are never read through a batch table)
+    for (int b = 0; b < B; ++b) std::memcpy(out + desc_off[b], descs[b], sizeof(int32_t) * (size_t)descs[b][H_OFF_STEPS]);
     // Sequence-major order (units inside a descriptor are already longest first): the workgroups that read one
     // sequence's K/V run together, so those rows stay in the XCD's L2 while they are needed.
     std::vector<SchedUnit> su;

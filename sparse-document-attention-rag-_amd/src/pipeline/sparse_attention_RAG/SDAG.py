@@ -72,6 +72,7 @@ def build_blocked_causal_mask_full(base_seq_len: int, max_new_tokens: int, sys_u
     if mask.device != torch.device(device):
         mask = mask.to(device)
     mask._sdag_desc = desc
+    mask._sdag_stamp = (mask._version, mask.data_ptr())  # in-place edits bump the version counter
     return mask
 
 
@@ -79,8 +80,11 @@ def _descriptor_of(prompt_mask: torch.Tensor, model_dtype: torch.dtype) -> Optio
     desc = getattr(prompt_mask, "_sdag_desc", None)
     if desc is not None and desc.L == prompt_mask.shape[0] and prompt_mask.dtype == torch.bool:
         # The attribute survives in-place edits of the tensor (an ablation that clears a block, say), and the
-        # reference always honours the tensor's contents (SDAG.py:167-171): use the remembered descriptor only if
-        # it still expands to exactly this mask (one L x L comparison on the GPU).
+        # reference always honours the tensor's contents (SDAG.py:167-171).  An untouched tensor (same storage, same
+        # version counter as when it was built) is taken at its word; an edited one only if the remembered descriptor
+        # still expands to exactly this mask (one L x L comparison on the GPU, with its host synchronisation).
+        if getattr(prompt_mask, "_sdag_stamp", None) == (prompt_mask._version, prompt_mask.data_ptr()):
+            return desc
         dev = _gpu_device(prompt_mask.device)
         if torch.equal(desc.materialize(dev), prompt_mask.to(dev)):
             return desc
@@ -431,7 +435,7 @@ def run_rag_with_doc_isolation_batch(model, tokenizer, queries: List[str], malic
         raise ValueError("one list of malicious documents and one of retrieved documents per query expected")
     if n == 0:
         return []
-    ids, descs = [], []
+    ids, layouts = [], []
     for query, mal, docs in zip(queries, malicious_docs_batch, retrieved_docs_batch):
         chat_str, sys_user_len, spans, qa_start, ranked_docs = build_rag_chat_and_spans(
             tokenizer=tokenizer, system_prompt=SYSTEM_PROMPT_RAG, user_template=USER_RAG_PROMPT, query=query,
@@ -441,7 +445,8 @@ def run_rag_with_doc_isolation_batch(model, tokenizer, queries: List[str], malic
             neighbors = compute_doc_knn_for_docs(ranker=ranker, docs=ranked_docs, k_neighbors=doc_neighbors_k)
         input_ids = tokenizer(chat_str, return_tensors="pt").to(device)["input_ids"]
         ids.append(input_ids)
-        descs.append(sdag_amd.from_spans(input_ids.size(1), sys_user_len, spans, qa_start, neighbors, max_items_per_unit=64))
+        layouts.append((input_ids.size(1), sys_user_len, spans, qa_start, neighbors))
+    descs = sdag_amd.from_spans_many(layouts, max_items_per_unit=64)  # (host threads: the builder is a C call)
     lengths = [int(t.size(1)) for t in ids]
     l_max = max(lengths)
     pad_id = getattr(tokenizer, "pad_token_id", None)  # any valid id: rows past a prompt's end are never read

@@ -171,3 +171,70 @@ def test_batch_table_stream_halves():
     for s in range(ns):
         seqs = steps[so[s]: so[s + 1], 3]
         assert (np.diff(seqs) >= 0).all()
+
+
+def test_random_layouts_expand_to_the_oracle_mask():
+    """Property test: for random prompts (documents of 0-120 tokens, gaps, an overlapping pair of spans, neighbour lists
+    with out-of-range and repeated ids or of the wrong length, which the reference ignores: SDAG.py:111), random unit
+    length limits and stream counts, the descriptor decoded from its word layout equals the oracle's mask bit for bit,
+    its streams cover every item once and a batch table of it is consistent."""
+    from hypothesis import given, settings, strategies as st
+
+    import sdag_amd
+    from oracle import sdag_ref
+
+    @st.composite
+    def prompts(draw):
+        n_docs = draw(st.integers(0, 7))
+        sys_len = draw(st.integers(0, 70))
+        lens = [draw(st.one_of(st.just(0), st.integers(1, 120))) for _ in range(n_docs)]
+        gaps = [draw(st.integers(0, 3)) for _ in range(n_docs)]
+        spans, pos = [], sys_len
+        for n, g in zip(lens, gaps):
+            spans.append((pos, pos + n))
+            pos += n + g
+        qa = pos
+        L = max(1, qa + draw(st.integers(0, 40)))
+        qa = min(qa, L)
+        if n_docs >= 2 and draw(st.booleans()):
+            a, b = spans[0]
+            spans[1] = (a + (b - a) // 2, max(spans[1][1], a + (b - a) // 2))
+        kind = draw(st.integers(0, 3))
+        nbr = None
+        if kind:
+            nbr = [[draw(st.integers(-2, n_docs + 1)) for _ in range(draw(st.integers(0, 3)))] for _ in range(n_docs)]
+            if kind == 3 and n_docs:
+                nbr = nbr[:-1]                      # wrong length: ignored wholesale
+        return L, sys_len, spans, qa, nbr, draw(st.integers(0, 5)), draw(st.sampled_from([0, 0, 1, 3, 64, 200]))
+
+    @settings(max_examples=120, deadline=None)
+    @given(prompts())
+    def check(p):
+        L, sys_len, spans, qa, nbr, T, ns = p
+        d = sdag_amd.from_spans(L, sys_len, spans, qa, nbr, max_items_per_unit=T, n_streams=ns)
+        ref = sdag_ref.mask_from_spans(L, sys_len, spans, qa, nbr)
+        assert np.array_equal(expand_descriptor(d.host), ref)
+        assert d.allowed_pairs == int(ref.sum()) and d.n_uniform_rows == int((ref.sum(1) == 0).sum())
+        w = d.host
+        seen, counts = check_schedule(w, int(w[H["OFF_STEPS"]]), int(w[H["OFF_STREAMS"]]), int(w[H["NSTREAMS"]]), lambda i: (w, 0))
+        assert len(seen) == d.n_units and counts.sum() == d.n_items
+        many = sdag_amd.from_spans_many([(L, sys_len, spans, qa, nbr)] * 3, max_items_per_unit=T, n_streams=ns)
+        assert all(np.array_equal(m.host, w) for m in many)   # the threaded builder gives the same words
+
+    check()
+
+
+def test_descriptor_builder_under_address_and_undefined_behaviour_sanitizers():
+    """``make asan`` in csrc/: the host-side builder and a C++ driver (desc_fuzz.cpp: random prompts into buffers of
+    exactly the requested size, expansion compared with the reference's rule, batch tables, refused arguments) built
+    with g++ -fsanitize=address,undefined and run; any finding aborts the run."""
+    import os
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None or shutil.which("make") is None:
+        pytest.skip("no host compiler")
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sparse-document-attention-rag-_amd", "csrc")
+    out = subprocess.run(["make", "-C", csrc, "asan", "ASAN_CASES=150"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "desc_fuzz ok" in out.stdout

@@ -452,3 +452,37 @@ def test_sharded_index_on_rccl_and_8_way_split_of_21m_corpus():
         dist.destroy_process_group()
     del C
     torch.cuda.empty_cache()
+
+
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """``bench.py --gpus 2 --config cfg5`` the way the round driver starts it (the launcher creates one process per
+    rank), both ranks on GPU 0 with the collectives over gloo: the sharded search (local top-k, one gather, merge), the
+    batched Near / Far kernel, the prefill launches and the decode steps all run for real at world size 2, and rank 0
+    prints ONE line with the keys of the one-rank line.  Started through the helper process of conftest.py, which has
+    never touched the GPU."""
+    import json
+    import os
+    import sys
+
+    from conftest import run_in_fresh_process
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["BENCH_REHEARSE_ON_ONE_GPU"] = "1"
+    lines = {}
+    for n in (2, 1):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--config", "cfg5", "--corpus-n", "400000",
+               "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-probe"]
+        res = run_in_fresh_process(cmd, env, 420)
+        if res is None:
+            pytest.skip("no helper process to start the benchmark from")
+        assert res["rc"] == 0, res["stderr"]
+        out = [l for l in res["stdout"].splitlines() if l.strip()]
+        assert len(out) == 1, res["stdout"]
+        lines[n] = json.loads(out[0])
+    two, one = lines[2], lines[1]
+    assert two["n_gpus"] == 2 and two["steps"] == 2 and two["scaling"] == "weak"
+    assert "sharded" in two["config"]["parallelism"] and two["config"]["parallelism"].startswith("dp2")
+    assert set(two) == set(one) and "cpu_baseline" not in two
+    assert set(two["stage"]) == set(one["stage"]) and set(two["roofline"]) == set(one["roofline"])
+    assert two["value"] > 0 and two["stage"]["retrieval_ms_per_batch"] > 0
