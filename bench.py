@@ -474,9 +474,32 @@ def main():
         probe["decode_us_b32"] = timed_us(lambda: sdag_amd.decode_attention(dq, k_[:, :, :S], v_[:, :, :S]), 20, 1)
         probe["decode_hbm_frac_b32"] = nb * 2 * Hkv * S * D * 2 / (probe["decode_us_b32"] * 1e-6) / HBM_PEAK
         probe["decode_us_b1"] = timed_us(lambda: sdag_amd.decode_attention(dq[:1], k_[:1, :, :S], v_[:1, :, :S]), 20, 1)
+        # the search with 256 queries in one call (two passes over the corpus of 128 queries each)
+        Q256 = torch.nn.functional.normalize(torch.randn((256, cfg["dim"]), device=dev), dim=1)
+        probe["retrieval_ms_nq256"] = timed_us(lambda: local_index.search_device(Q256, k), 5, 1) / 1e3
+        probe["retrieval_hbm_frac_nq256"] = (local_index.ntotal * cfg["dim"] * (2 if local_index.two_stage else 4) * 2
+                                             / (probe["retrieval_ms_nq256"] * 1e-3)) / HBM_PEAK
+        del Q256
         if args.config != "cfg4":
-            # cfg 4 (20 documents x 380 tokens, 2 neighbours each, L = 7710) as a batch of 8: MFMA-bound by the accounting
             del pq
+            # the "~4k-token context" variant of the prompt: 10 documents x 380 tokens, L = 3900, a batch of 32
+            spans39, pos39 = [], cfg["sys_len"]
+            for _ in range(10):
+                spans39.append((pos39, pos39 + 380))
+                pos39 += 381
+            L39 = pos39 + 30
+            g = torch.Generator(device=dev).manual_seed(39)
+            mk = lambda h: torch.randn((nb, L39, h, D), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16).transpose(1, 2)
+            q39, k39, v39 = mk(Hq), mk(Hkv), mk(Hkv)
+            o39 = torch.empty((nb, L39, Hq, D), device=dev, dtype=torch.bfloat16)
+            d39 = sdag_amd.from_spans(L39, cfg["sys_len"], spans39, pos39, None, max_items_per_unit=64)
+            call39 = sdag_amd.BoundBatchAttention(q39, k39, v39, sdag_amd.BatchDescriptor([d39] * nb), o39)
+            us39 = timed_us(lambda: call39(stream), 5, 1)
+            probe["sdag_L3900_us_per_launch"] = us39
+            probe["sdag_ms_per_query_L3900"] = us39 * nl / nb / 1e3
+            probe["sdag_L3900_hbm_frac"] = nb * L39 * (2 * Hq + 2 * Hkv) * D * 2 / (us39 * 1e-6) / HBM_PEAK
+            del q39, k39, v39, o39, call39
+            # cfg 4 (20 documents x 380 tokens, 2 neighbours each, L = 7710) as a batch of 8: MFMA-bound by the accounting
             c4 = CONFIGS["cfg4"]
             p4 = prompts_of(c4)[:8]
             L4 = p4[0][2]

@@ -24,6 +24,20 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 240 rocprofv3 --pmc $ctr --output-format csv -d $out/${tag}_pmc_$ctr -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-probe > /dev/null 2> $out/${tag}_pmc_$ctr.err || { echo "pmc $ctr failed"; tail -5 $out/${tag}_pmc_$ctr.err; exit 1; }
 done
 python3 $root/tools/collect_traffic.py $(ls $out/${tag}_pmc_FETCH_SIZE/*/*counter_collection.csv | head -1) $(ls $out/${tag}_pmc_WRITE_SIZE/*/*counter_collection.csv | head -1) $out/${tag}_traffic.json cfg3 "$tag" > /dev/null || exit 1
+# the same two passes for the long-context workload (its roofline.traffic)
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $out/${tag}_pmc4_$ctr
+  timeout -s KILL 240 rocprofv3 --pmc $ctr --output-format csv -d $out/${tag}_pmc4_$ctr -- python3 $root/bench.py --config cfg4 --steps 1 --warmup 0 --no-cpu-baseline --no-probe > /dev/null 2> $out/${tag}_pmc4_$ctr.err || { echo "pmc cfg4 $ctr failed"; tail -5 $out/${tag}_pmc4_$ctr.err; exit 1; }
+done
+python3 $root/tools/collect_traffic.py $(ls $out/${tag}_pmc4_FETCH_SIZE/*/*counter_collection.csv | head -1) $(ls $out/${tag}_pmc4_WRITE_SIZE/*/*counter_collection.csv | head -1) $out/${tag}_traffic.json cfg4 "$tag" > /dev/null || exit 1
+# the search with 32 .. 1024 queries per call under the kernel trace
+rm -rf $out/${tag}_trace_dense
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace_dense -- python3 $root/tools/dense_microbench.py 2626916 1024 3 10 wide > $out/${tag}_dense_wide.txt 2> $out/${tag}_trace_dense.err || { echo "trace dense failed"; tail -5 $out/${tag}_trace_dense.err; exit 1; }
+python3 $root/tools/summarize_rocprof.py $(ls $out/${tag}_trace_dense/*/*kernel_stats.csv | head -1) 12 > $out/${tag}_dense_wide_kernel_stats.txt || exit 1
+# decode attention over batch sizes
+timeout -k 10 200 python3 $root/tools/decode_sweep.py 3100 > $out/${tag}_decode_sweep.txt 2>&1 || { echo "decode sweep failed"; exit 1; }
+# the sharded-corpus workload with the whole 21,015,324-row corpus on this one GPU
+timeout -k 10 600 python3 $root/bench.py --config cfg5 --steps 3 --warmup 1 --no-cpu-baseline --no-probe > $out/${tag}_bench_cfg5_21m.json 2> $out/${tag}_bench_cfg5.err || { echo "cfg5 failed"; tail -5 $out/${tag}_bench_cfg5.err; exit 1; }
 for cfg in cfg3 cfg4; do
   rm -rf $out/${tag}_sq_$cfg
   timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $out/${tag}_sq_$cfg -- python3 $root/bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-probe > /dev/null 2> $out/${tag}_sq_$cfg.err || { echo "sq $cfg failed"; tail -5 $out/${tag}_sq_$cfg.err; exit 1; }
