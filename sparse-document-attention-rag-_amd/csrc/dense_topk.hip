@@ -78,7 +78,10 @@ static_assert(MAX_WG % 64 == 0, "stripe maxima are held 64 per register");
 //           from the L2, sit in a shallow ring of their own (NSTQ).  Waves 0-3 issue only corpus pieces and waves 4-7
 //           only query pieces: the s_waitcnt counter is per wave and in issue order, so a wave that issued both could
 //           not wait for a recent query piece without also waiting for every older corpus piece.
-template <int NQB, int NW>
+//   THR: the threshold scan (see dense_scan): no per-query lists, one buffer of THR_CB survivors per workgroup instead,
+//           so the LDS takes the rings of up to 8 query blocks (256 queries per pass over the corpus).
+constexpr int THR_CB = 1024;                // survivors a workgroup buffers before it appends them to the global lists
+template <int NQB, int NW, bool THR = false>
 struct ScanCfg {
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     static_assert(NQB % (NW / 4) == 0, "the query blocks are split over the wave groups");
@@ -98,20 +101,51 @@ struct ScanCfg {
     static constexpr int WAIT_C = SPLIT ? PPW_C * (NSTC - 2) : (PPW_C + PPW_Q) * (NST - 2);
     // candidate list capacity per query: 64, or what the LDS leaves (a list is compacted when it could overflow in the
     // next filter round, so a short list is compacted after every few survivors)
-    static constexpr int CAP_ROOM = (160 * 1024 - RING - 3 * QTW * 4) / (QTW * 8);
+    static constexpr int CAP_ROOM = THR ? 64 : (160 * 1024 - RING - 3 * QTW * 4) / (QTW * 8);
     static constexpr int CAP = CAP_ROOM < 64 ? CAP_ROOM : 64;
-    static_assert(CAP >= (NQB == MAX_NQB ? WIDE_KS : MAX_K) + PUSH_MAX, "a list holds what is kept plus one round of survivors");
+    static_assert(THR || CAP >= (NQB == MAX_NQB ? WIDE_KS : MAX_K) + PUSH_MAX, "a list holds what is kept plus one round of survivors");
     static constexpr int LPW = QTW / NW;                 // lists a wave looks after
     static constexpr int OFF_CS = RING;                  // float cand_s[QTW][CAP]
     static constexpr int OFF_CI = OFF_CS + QTW * CAP * 4;  // int   cand_i[QTW][CAP]
     static constexpr int OFF_CNT = OFF_CI + QTW * CAP * 4; // int   cnt[QTW]
     static constexpr int OFF_TS = OFF_CNT + QTW * 4;     // float thr_s[QTW]
     static constexpr int OFF_TI = OFF_TS + QTW * 4;      // int   thr_i[QTW]
-    static constexpr int LDS = OFF_TI + QTW * 4;
+    // threshold scan: int buf_q[THR_CB], float buf_s[THR_CB], int buf_i[THR_CB], int buf_n
+    static constexpr int OFF_BQ = RING;
+    static constexpr int OFF_BS = OFF_BQ + THR_CB * 4;
+    static constexpr int OFF_BI = OFF_BS + THR_CB * 4;
+    static constexpr int OFF_BN = OFF_BI + THR_CB * 4;
+    static constexpr int LDS = THR ? OFF_BN + 16 : OFF_TI + QTW * 4;
     static constexpr int WG_PER_CU = SPLIT ? 1 : SDAG_SCAN_WG_PER_CU;
     static_assert(LDS <= 160 * 1024, "LDS of a compute unit");
-    static_assert(LPW <= 64, "a wave checks its lists' lengths one per lane");
+    static_assert(THR || LPW <= 64, "a wave checks its lists' lengths one per lane");
+    static_assert(!THR || SPLIT, "the threshold scan runs 8 waves");
 };
+
+// What the threshold scan reads and writes beside the corpus and the queries (all for the pass's queries).
+struct ThrArgs {
+    const float* pilot_s;  // [nq][m]: the m best approximate scores of a sample of the corpus, best first
+    const int64_t* pilot_i;  // [nq][m]: their rows (-1 = the sample held fewer rows)
+    int m;
+    const float* eps;      // [nq]: an approximate score is within eps of the exact one
+    float* cand_s;         // [nq][cap]: approximate scores of the rows at or above the query's threshold
+    int* cand_i;           // [nq][cap]: those rows
+    int* cand_n;           // [nq]: how many there are (may exceed cap: the rest was dropped), zero when the pass starts
+    int cap;
+    int* flag;             // set when a workgroup had to drop survivors
+    // block maxima (MODE 2): entry e = 4 * sampled tile + row group of a query sits at ((e / bm_m) * bm_qtw + query) * bm_m
+    // + e % bm_m, the layout the merge kernel reads as lists of bm_m entries; bm_i takes e (prefilled with -1)
+    float* bm_s;
+    int* bm_i;
+    int bm_m, bm_qtw;
+};
+
+// The threshold of a query in the threshold scan: the sample's m-th best approximate score less 2 eps (every row whose
+// approximate score reaches the line is a candidate); without m sample rows every row is one.
+__device__ __forceinline__ float thr_of(const ThrArgs& a, int q) {
+    return a.pilot_i[(int64_t)q * a.m + a.m - 1] >= 0 ? a.pilot_s[(int64_t)q * a.m + a.m - 1] - 2.0f * a.eps[q] : -FLT_MAX;
+}
+constexpr int MODE_LISTS = 0, MODE_THR = 1, MODE_BMAX = 2;
 
 __device__ __forceinline__ bool better(float s, int64_t i, float s2, int64_t i2) {
     return (s > s2) || (s == s2 && i < i2);
@@ -172,15 +206,28 @@ __device__ __forceinline__ void compact_list(unsigned char* smem, int j, int k, 
 // (64 dimensions per 128-byte stage, one v_mfma_f32_32x32x16_bf16 per 16 dimensions): approximate scores, used only
 // to pick candidates for exact rescoring.  run_flag (optional): the kernel does nothing when *run_flag == 0.
 // Partial lists: part[(stripe * QTW + query) * k + t].
-template <bool BF16, int NQB, int NW>
-__global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW>::WG_PER_CU)) void dense_scan(const void* __restrict__ Qv, int nq, const void* __restrict__ Cv,
+//
+// tile_step > 1: the scan walks every tile_step-th 128-row tile of the corpus only (a sample: rows_per_wg counts sampled
+// rows).
+// THR = true (the threshold scan, for many queries at once): instead of keeping the best k per stripe and query, the
+// scan appends every row whose approximate score reaches the query's threshold (ThrArgs) to that query's global
+// candidate list, through a workgroup-wide buffer in LDS; k, part_s and part_i are not used.  No lists, no compaction
+// and, tile by tile, no barrier: with thresholds taken from a sample so that a few hundred rows of the whole corpus
+// pass, a workgroup sees a handful of survivors per tile.
+// MODE_BMAX (the pilot of the threshold scan, over a sample of the tiles): per query and 32-row block of every tile the
+// largest approximate score goes to ta.bm_s; the m-th largest of those (scores of m distinct rows) is the sample
+// statistic the thresholds are taken from.  No lists, no atomics.
+template <bool BF16, int NQB, int NW, int MODE>
+__global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW, MODE != 0>::WG_PER_CU)) void dense_scan(const void* __restrict__ Qv, int nq, const void* __restrict__ Cv,
                                                      int64_t N, int d, int k, int rows_per_wg,
                                                      float* __restrict__ part_s, int* __restrict__ part_i,
-                                                     const int* __restrict__ run_flag, int q_row_bytes, int q_kc_bytes) {
+                                                     const int* __restrict__ run_flag, int q_row_bytes, int q_kc_bytes,
+                                                     int tile_step, const ThrArgs ta) {
     // Query j's 128 bytes of stage kc sit at Q + j * q_row_bytes + kc * q_kc_bytes (row-major queries: d * element size
     // and 128; slab-major, see query_prepare_kernel: 128 and 128 * queries per pass).
     if (run_flag && *run_flag == 0) return;
-    using CFG = ScanCfg<NQB, NW>;
+    constexpr bool THR = MODE == MODE_THR;
+    using CFG = ScanCfg<NQB, NW, MODE != 0>;
     constexpr int QTW = CFG::QTW, QPW = CFG::QPW, CAP = CFG::CAP, LPW = CFG::LPW;
     constexpr int OFF_CS = CFG::OFF_CS, OFF_CI = CFG::OFF_CI, OFF_CNT = CFG::OFF_CNT, OFF_TS = CFG::OFF_TS, OFF_TI = CFG::OFF_TI;
     constexpr int KCE = BF16 ? KC16 : KC;  // elements per stage
@@ -194,18 +241,32 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW>::WG_PER_CU)) void dense_
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     __builtin_assume(w >= 0 && w < NW);
     const int rg = w & 3, qg = w >> 2;  // the wave's 32 rows of a tile, its group of query blocks
-    const int64_t wg_row0 = (int64_t)blockIdx.x * rows_per_wg;
-    const int64_t wg_rows = min((int64_t)rows_per_wg, N - wg_row0);
-    const int ntile = (int)((wg_rows + TR - 1) / TR);
+    // this workgroup's tiles: sampled tile t of the stripe is corpus tile (tile0 + t) * tile_step
+    const int64_t tile0 = (int64_t)blockIdx.x * (rows_per_wg / TR);
+    const int64_t n_sampled = ((N + TR - 1) / TR + tile_step - 1) / tile_step;
+    const int ntile = (int)max((int64_t)0, min((int64_t)(rows_per_wg / TR), n_sampled - tile0));
     const int nkc = d / KCE;
     const int S = ntile * nkc;
+    auto tile_row0 = [&](int tile) { return (tile0 + tile) * tile_step * TR; };
 
-    for (int j = tid; j < QTW; j += 64 * NW) {
-        reinterpret_cast<int*>(smem + OFF_CNT)[j] = 0;
-        reinterpret_cast<float*>(smem + OFF_TS)[j] = -INFINITY;
-        reinterpret_cast<int*>(smem + OFF_TI)[j] = INT_MAX;
+    if constexpr (MODE != MODE_LISTS) {
+        if (tid == 0) *reinterpret_cast<int*>(smem + CFG::OFF_BN) = 0;
+    } else {
+        for (int j = tid; j < QTW; j += 64 * NW) {
+            reinterpret_cast<int*>(smem + OFF_CNT)[j] = 0;
+            reinterpret_cast<float*>(smem + OFF_TS)[j] = -INFINITY;
+            reinterpret_cast<int*>(smem + OFF_TI)[j] = INT_MAX;
+        }
     }
     lds_barrier();
+    if (S == 0) {  // (a stripe beyond the sample: nothing to scan, fill lists to write)
+        if constexpr (MODE == MODE_LISTS)
+            for (int e = tid; e < QTW * k; e += 64 * NW) {
+                part_s[(int64_t)blockIdx.x * QTW * k + e] = -FLT_MAX;
+                part_i[(int64_t)blockIdx.x * QTW * k + e] = -1;
+            }
+        return;
+    }
 
     // ---- LDS-DMA geometry.  A wave instruction writes 1 KiB = 8 rows x 128 B; lane -> (row lane >> 3,
     // physical chunk lane & 7); the source chunk is physical ^ ((row >> 1) & 7).  A corpus stage is 16 pieces (rows
@@ -217,7 +278,7 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW>::WG_PER_CU)) void dense_
         const int tile = s / nkc, kc = s - tile * nkc;
         unsigned char* sb = smem + (s % CFG::NSTC) * CFG::C_STRIDE;
         const int rl = c * 8 + dr;  // row inside the tile (the swizzle only looks at its low bits)
-        int64_t row = wg_row0 + (int64_t)tile * TR + rl;
+        int64_t row = tile_row0(tile) + rl;
         row = row < N ? row : N - 1;
         const int csrc = dc ^ ((rl >> 1) & 7);
         const unsigned char* src = C + (row * d + kc * KCE) * ES + csrc * 16;
@@ -272,10 +333,36 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW>::WG_PER_CU)) void dense_
     const int b_off = (qg * QPW * 32 + r) * 128;
 
     f32x16 acc[QPW];
+    float thr[QPW];  // threshold scan: this lane's queries' thresholds
 #pragma unroll
-    for (int qb = 0; qb < QPW; ++qb)
+    for (int qb = 0; qb < QPW; ++qb) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[qb][i] = 0.f;
+        thr[qb] = 0.f;
+        if constexpr (THR) {
+            const int qi = (qg * QPW + qb) * 32 + r;
+            thr[qb] = qi < nq ? thr_of(ta, qi) : INFINITY;
+        }
+    }
+    // Threshold scan: the workgroup's buffered survivors go to the queries' global lists (every thread takes some; the
+    // waits for the atomics' results drain this wave's loads in flight, which is why it happens rarely).
+    auto flush_buffer = [&]() {
+        lds_barrier();
+        const int n_raw = *reinterpret_cast<const int*>(smem + CFG::OFF_BN);
+        if (n_raw > THR_CB && tid == 0) atomicOr(ta.flag, 1);  // survivors were dropped: the exact scan has to answer
+        const int n = n_raw < THR_CB ? n_raw : THR_CB;
+        for (int e = tid; e < n; e += 64 * NW) {
+            const int q = reinterpret_cast<const int*>(smem + CFG::OFF_BQ)[e];
+            const int pos = atomicAdd(ta.cand_n + q, 1);
+            if (pos < ta.cap) {
+                ta.cand_s[(int64_t)q * ta.cap + pos] = reinterpret_cast<const float*>(smem + CFG::OFF_BS)[e];
+                ta.cand_i[(int64_t)q * ta.cap + pos] = reinterpret_cast<const int*>(smem + CFG::OFF_BI)[e];
+            }
+        }
+        lds_barrier();
+        if (tid == 0) *reinterpret_cast<int*>(smem + CFG::OFF_BN) = 0;
+        lds_barrier();
+    };
 
     if constexpr (CFG::SPLIT) {
         if (w < 4) {
@@ -363,6 +450,11 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW>::WG_PER_CU)) void dense_
             issue_corpus(s + NST - 1);
             issue_queries(s + NST - 1);
         }
+        if constexpr (THR) {
+            // between a stage's barrier and a tile's end nobody appends: every wave reads the same count here
+            if (kc == 0 && __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + CFG::OFF_BN)) > THR_CB / 2)
+                flush_buffer();
+        }
         const unsigned char* sbc = smem + (s % CFG::NSTC) * CFG::C_STRIDE;
         const unsigned char* sbq = smem + CFG::Q_BASE + (s % CFG::NSTQ) * CFG::Q_STRIDE;
 #pragma unroll
@@ -403,9 +495,51 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW>::WG_PER_CU)) void dense_
         if (++kc < nkc) continue;
         kc = 0;
         // ---- tile finished
-        const int64_t row_base = wg_row0 + (int64_t)tile * TR + rg * 32 + 4 * h;
+        const int64_t row_base = tile_row0(tile) + rg * 32 + 4 * h;
         ++tile;
-        if (!(SDAG_SCAN_EXP & 1)) {
+        if constexpr (MODE == MODE_BMAX) {
+#pragma unroll
+            for (int qb = 0; qb < QPW; ++qb) {
+                float mx = acc[qb][0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) mx = fmaxf(mx, acc[qb][i]);
+                float other = mx;
+                swap_halves(mx, other);  // mx: own half | other half's value -> both halves end with the block's maximum
+                mx = fmaxf(mx, other);
+                const int qi = (qg * QPW + qb) * 32 + r;
+                if (h == 0 && qi < nq) {
+                    const int64_t e = (tile0 + tile - 1) * 4 + rg;  // (tile was advanced)
+                    const int64_t at = ((e / ta.bm_m) * ta.bm_qtw + qi) * ta.bm_m + e % ta.bm_m;
+                    ta.bm_s[at] = mx;
+                    ta.bm_i[at] = (int)e;
+                }
+            }
+        } else if constexpr (THR) {
+            if (!(SDAG_SCAN_EXP & 1)) {
+                bool mine = false;
+#pragma unroll
+                for (int qb = 0; qb < QPW; ++qb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) mine |= acc[qb][i] >= thr[qb] && row_base + (i & 3) + 8 * (i >> 2) < N;
+                if (__builtin_amdgcn_ballot_w64(mine) != 0) {
+                    int* bn = reinterpret_cast<int*>(smem + CFG::OFF_BN);
+#pragma unroll
+                    for (int qb = 0; qb < QPW; ++qb)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int64_t row = row_base + (i & 3) + 8 * (i >> 2);
+                            if (acc[qb][i] >= thr[qb] && row < N) {  // (a score that is not a number fails the test)
+                                const int pos = atomicAdd(bn, 1);
+                                if (pos < THR_CB) {
+                                    reinterpret_cast<int*>(smem + CFG::OFF_BQ)[pos] = (qg * QPW + qb) * 32 + r;
+                                    reinterpret_cast<float*>(smem + CFG::OFF_BS)[pos] = acc[qb][i];
+                                    reinterpret_cast<int*>(smem + CFG::OFF_BI)[pos] = (int)row;
+                                }
+                            }
+                        }
+                }
+            }
+        } else if (!(SDAG_SCAN_EXP & 1)) {
 #pragma unroll
             for (int round = 0; round < 4; ++round) {
                 push_round(round * 4, row_base);
@@ -421,6 +555,11 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW>::WG_PER_CU)) void dense_
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
+    if constexpr (MODE == MODE_BMAX) return;
+    if constexpr (THR) {
+        flush_buffer();
+        return;
+    }
     for (int jj = 0; jj < LPW; ++jj) compact_list<CFG>(smem, w * LPW + jj, k, lane);
     lds_barrier();
     // ---- write this stripe's best k per query (fill: -FLT_MAX / -1)
@@ -555,9 +694,10 @@ inline int scan_keep(int k) {
 // clears the fallback flags of the call's query batches (n_flags of them).
 __global__ __launch_bounds__(256) void query_prepare_kernel(const float* __restrict__ Q, int d, const float* __restrict__ cmax,
                                                             unsigned short* __restrict__ Q16, float* __restrict__ eps,
-                                                            int* __restrict__ flags, int n_flags, int qtw) {
+                                                            int* __restrict__ flags, int n_flags, int qtw, int* __restrict__ cand_n) {
     __shared__ float red[256];
     const int q = blockIdx.x, tid = threadIdx.x;
+    if (cand_n && tid == 0) cand_n[q] = 0;  // the query's candidate list of the threshold scan starts empty
     if (q == 0)
         for (int f = tid; f < n_flags; f += 256) flags[f] = 0;
     float ss = 0.f;
@@ -787,6 +927,156 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
     if (tid == 0 && bad_s) atomicOr(flag, 1);
 }
 
+// The k-th largest of the keys a 256-thread block holds (8 per thread, 0 = none), ties counted with multiplicity, built
+// from the top bit down like wave_kth_largest; the waves' counts meet in LDS (two alternating sets of four words, one
+// barrier per bit).  Every thread returns the same value; 0 when fewer than k keys are set.
+__device__ __forceinline__ unsigned block_kth_largest(const unsigned (&key)[8], int k, int* red /* [8] */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned prefix = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned trial = prefix | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[i] >= trial));
+        int* r4 = red + 4 * (bit & 1);
+        if (lane == 0) r4[w] = cnt;
+        __syncthreads();
+        if (r4[0] + r4[1] + r4[2] + r4[3] >= k) prefix = trial;
+    }
+    return prefix;
+}
+
+// Rescoring for the threshold scan: the candidates of query q are the rows in its global list (approximate score at
+// or above T = s_m - 2 eps, s_m the sample statistic the threshold was taken from), ALL such rows of the corpus unless
+// something overflowed.  If at least k of them reach s_m, the k-th largest approximate score in the list is a_k, the
+// k-th best approximate score of the whole corpus, and a_k >= s_m = T + 2 eps; every row of the exact top k has an
+// approximate score >= a_k - 2 eps >= T, so it is in the list, and only the entries at or above the line a_k - 2 eps
+// need their exact score.  Otherwise (fewer than k reach s_m, more than RS2_HI do, the list overflowed or the scan
+// dropped survivors) the flag makes the exact scan answer.  Without a sample statistic the threshold is -FLT_MAX, the
+// list is the whole corpus and every entry is scored.
+// grid (RS_G, queries): every block finds the line on its own (the list's scores at or above s_m, up to RS2_HI of
+// them), takes the entries at list positions g, g + RS_G, ... that reach it, scores them in chunks of RS_CB, ranks them
+// and writes its best k as partial list g of the query, in the layout the merge kernel reads.
+constexpr int RS2_MAX = 256;   // list entries one block looks at: list capacity / RS_G
+constexpr int RS2_HI = 2048;   // scores at or above s_m a block can select among (8 per thread)
+__global__ __launch_bounds__(256) void rescore_cand_kernel(const float* __restrict__ Q, const float* __restrict__ C, int d, int k,
+                                                           const ThrArgs ta, int q_stride, float* __restrict__ blk_s,
+                                                           int* __restrict__ blk_i) {
+    __shared__ __attribute__((aligned(16))) float rows[RS_CB * RS_RW];
+    __shared__ __attribute__((aligned(16))) float qs[RS_DC];
+    __shared__ int cand[RS_CB];
+    __shared__ float res_s[RS2_MAX];
+    __shared__ int res_i[RS2_MAX];
+    __shared__ int sel[RS2_MAX];
+    __shared__ int red[8];
+    __shared__ int n_hi_s, n_sel_s;
+    const int g = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
+    const int n_raw = ta.cand_n[q];
+    const int n_all = n_raw < ta.cap ? n_raw : ta.cap;
+    const float* ls = ta.cand_s + (int64_t)q * ta.cap;
+    const int* li = ta.cand_i + (int64_t)q * ta.cap;
+    const bool sampled = ta.pilot_i[(int64_t)q * ta.m + ta.m - 1] >= 0;
+    const float s_m = ta.pilot_s[(int64_t)q * ta.m + ta.m - 1];
+    if (tid == 0) { n_hi_s = 0; n_sel_s = 0; }
+    __syncthreads();
+    // ---- the line: a_k - 2 eps, a_k = the k-th largest of the list's scores that reach s_m
+    float line = -FLT_MAX;
+    bool bad = n_raw > ta.cap;
+    if (sampled) {
+        unsigned key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int e = tid; e < n_all; e += 256) {
+            const float x = ls[e];
+            if (x >= s_m) {
+                const int pos = atomicAdd(&n_hi_s, 1);
+                // thread (pos % 256) register (pos / 256) would need a shuffle: park the value in LDS instead
+                if (pos < RS2_HI) rows[pos] = x;
+            }
+        }
+        __syncthreads();
+        const int n_hi = n_hi_s;
+        if (n_hi < k || n_hi > RS2_HI) {
+            bad = true;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (tid + 256 * i < n_hi) key[i] = float_key(rows[tid + 256 * i]);
+            __syncthreads();  // (rows is reused below)
+            line = key_float(block_kth_largest(key, k, red)) - 2.0f * ta.eps[q];
+        }
+    }
+    if (bad && g == 0 && tid == 0) atomicOr(ta.flag, 1);
+    // ---- this block's entries at or above the line
+    if (g + tid * RS_G < n_all && tid < RS2_MAX && !(bad && sampled)) {
+        if (ls[g + tid * RS_G] >= line) sel[atomicAdd(&n_sel_s, 1)] = li[g + tid * RS_G];
+    }
+    __syncthreads();
+    const int n_mine = n_sel_s;
+    constexpr int PER_ROW = RS_DC / 4, PIECES = RS_CB * PER_ROW / 256;
+    for (int c0 = 0; c0 < n_mine; c0 += RS_CB) {
+        const int n = n_mine - c0 < RS_CB ? n_mine - c0 : RS_CB;
+        __syncthreads();  // the previous chunk's rows and candidates have been consumed
+        if (tid < n) cand[tid] = sel[c0 + tid];
+        __syncthreads();
+        f32x4 pre[PIECES], preq;
+        auto fetch = [&](int dc) {
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int e = tid + 256 * i, rr = e / PER_ROW, c4 = e % PER_ROW;
+                if (rr < n && dc + 4 * c4 < d) pre[i] = *reinterpret_cast<const f32x4*>(C + (int64_t)cand[rr] * d + dc + 4 * c4);
+            }
+            if (tid < PER_ROW && dc + 4 * tid < d) preq = *reinterpret_cast<const f32x4*>(Q + (int64_t)q * d + dc + 4 * tid);
+        };
+        float acc = 0.f;
+        fetch(0);
+        for (int dc = 0; dc < d; dc += RS_DC) {
+            const int dn = d - dc < RS_DC ? d - dc : RS_DC;  // a multiple of 64
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int e = tid + 256 * i, rr = e / PER_ROW, c4 = e % PER_ROW;
+                if (rr < n && dc + 4 * c4 < d) *reinterpret_cast<f32x4*>(rows + rr * RS_RW + 4 * c4) = pre[i];
+            }
+            if (tid < PER_ROW && dc + 4 * tid < d) *reinterpret_cast<f32x4*>(qs + 4 * tid) = preq;
+            __syncthreads();
+            if (dc + RS_DC < d) fetch(dc + RS_DC);
+            if (tid < n) {
+                const float* rp = rows + tid * RS_RW;
+                for (int j = 0; j < dn; j += 4) {  // the one fp32 FMA chain over the dimensions in order
+                    const f32x4 cv = *reinterpret_cast<const f32x4*>(rp + j);
+                    const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + j);
+                    acc = __builtin_fmaf(cv[0], qv[0], acc);
+                    acc = __builtin_fmaf(cv[1], qv[1], acc);
+                    acc = __builtin_fmaf(cv[2], qv[2], acc);
+                    acc = __builtin_fmaf(cv[3], qv[3], acc);
+                }
+            }
+        }
+        if (tid < n) {
+            const bool ok = acc == acc;  // a NaN score is never returned: it becomes a fill entry
+            res_s[c0 + tid] = ok ? acc : -FLT_MAX;
+            res_i[c0 + tid] = ok ? cand[tid] : -1;
+        }
+    }
+    __syncthreads();
+    // ---- this block's best k, sorted (equal entries - fills - ordered by position: every rank is taken exactly once)
+    const int64_t ob = ((int64_t)g * q_stride + q) * k;
+    for (int c = tid; c < n_mine; c += 256) {
+        const float sc = res_s[c];
+        const int ic = res_i[c];
+        int rank = 0;
+        for (int j2 = 0; j2 < n_mine; ++j2)
+            rank += (better(res_s[j2], res_i[j2], sc, ic) || (res_s[j2] == sc && res_i[j2] == ic && j2 < c)) ? 1 : 0;
+        if (rank < k) {
+            blk_s[ob + rank] = sc;
+            blk_i[ob + rank] = ic;
+        }
+    }
+    if (tid < k && tid >= n_mine) {
+        blk_s[ob + tid] = -FLT_MAX;
+        blk_i[ob + tid] = -1;
+    }
+}
+
 // ---- small similarity ops ---------------------------------------------------------------------------
 __global__ void gram_kernel(const float* __restrict__ E, int n, int d, float* __restrict__ sims) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -866,27 +1156,42 @@ inline ScanPlan plan_scan(int64_t N, int nqb = 1) {
 using namespace sdag;
 
 namespace {
-template <bool BF16, int NQB, int NW>
+// slab_width: 0 = the queries are a row-major [nq][d] matrix, else they are stored slab-major for passes of slab_width
+// queries (see query_prepare_kernel) and Q points at the first query of the launch inside its pass.
+template <bool BF16, int NQB, int NW, int MODE>
 int launch_scan_cfg(int n_wg, hipStream_t st, const void* Q, int nqt, const void* C, int64_t N, int d, int k, int rows_per_wg,
-                    float* part_s, int* part_i, const int* run_flag, bool slab_major) {
-    using CFG = ScanCfg<NQB, NW>;
+                    float* part_s, int* part_i, const int* run_flag, int slab_width, int tile_step, const ThrArgs& ta) {
+    using CFG = ScanCfg<NQB, NW, MODE != 0>;
     const int es = BF16 ? 2 : 4;
-    const int q_row_bytes = slab_major ? 128 : d * es, q_kc_bytes = slab_major ? 128 * CFG::QTW : 128;
-    SDAG_HIP_CHECK(hipFuncSetAttribute((const void*)dense_scan<BF16, NQB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS));
-    hipLaunchKernelGGL((dense_scan<BF16, NQB, NW>), dim3(n_wg), dim3(64 * NW), CFG::LDS, st, Q, nqt, C, N, d, k, rows_per_wg, part_s,
-                       part_i, run_flag, q_row_bytes, q_kc_bytes);
+    const int q_row_bytes = slab_width ? 128 : d * es, q_kc_bytes = slab_width ? 128 * slab_width : 128;
+    SDAG_HIP_CHECK(hipFuncSetAttribute((const void*)dense_scan<BF16, NQB, NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS));
+    hipLaunchKernelGGL((dense_scan<BF16, NQB, NW, MODE>), dim3(n_wg), dim3(64 * NW), CFG::LDS, st, Q, nqt, C, N, d, k, rows_per_wg, part_s,
+                       part_i, run_flag, q_row_bytes, q_kc_bytes, tile_step, ta);
     SDAG_HIP_CHECK(hipGetLastError());
     return SDAG_OK;
 }
 
-// One pass of the scan over the corpus for nqt <= 32 nqb queries.
+// One pass of the list scan over the corpus (or a sample of it) for nqt <= 32 nqb queries.
 template <bool BF16>
 int launch_scan(int nqb, int n_wg, hipStream_t st, const void* Q, int nqt, const void* C, int64_t N, int d, int k, int rows_per_wg,
-                float* part_s, int* part_i, const int* run_flag, bool slab_major) {
+                float* part_s, int* part_i, const int* run_flag, int slab_width, int tile_step = 1) {
+    const ThrArgs none = {};
     switch (nqb) {
-        case 1: return launch_scan_cfg<BF16, 1, 4>(n_wg, st, Q, nqt, C, N, d, k, rows_per_wg, part_s, part_i, run_flag, slab_major);
-        case 2: return launch_scan_cfg<BF16, 2, 8>(n_wg, st, Q, nqt, C, N, d, k, rows_per_wg, part_s, part_i, run_flag, slab_major);
-        case 4: return launch_scan_cfg<BF16, 4, 8>(n_wg, st, Q, nqt, C, N, d, k, rows_per_wg, part_s, part_i, run_flag, slab_major);
+        case 1: return launch_scan_cfg<BF16, 1, 4, MODE_LISTS>(n_wg, st, Q, nqt, C, N, d, k, rows_per_wg, part_s, part_i, run_flag, slab_width, tile_step, none);
+        case 2: return launch_scan_cfg<BF16, 2, 8, MODE_LISTS>(n_wg, st, Q, nqt, C, N, d, k, rows_per_wg, part_s, part_i, run_flag, slab_width, tile_step, none);
+        case 4: return launch_scan_cfg<BF16, 4, 8, MODE_LISTS>(n_wg, st, Q, nqt, C, N, d, k, rows_per_wg, part_s, part_i, run_flag, slab_width, tile_step, none);
+    }
+    return fail(SDAG_ERR_ARG, "bad pass width");
+}
+
+// One pass of the threshold scan (bf16 copies) for nqt <= 32 nqb queries, or (tile_step > 1) its pilot over a sample.
+template <int MODE>
+int launch_thr_scan(int nqb, int n_wg, hipStream_t st, const void* Q16, int nqt, const void* C16, int64_t N, int d, int rows_per_wg,
+                    int tile_step, const ThrArgs& ta) {
+    switch (nqb) {
+        case 2: return launch_scan_cfg<true, 2, 8, MODE>(n_wg, st, Q16, nqt, C16, N, d, 0, rows_per_wg, nullptr, nullptr, nullptr, 32 * nqb, tile_step, ta);
+        case 4: return launch_scan_cfg<true, 4, 8, MODE>(n_wg, st, Q16, nqt, C16, N, d, 0, rows_per_wg, nullptr, nullptr, nullptr, 32 * nqb, tile_step, ta);
+        case 8: return launch_scan_cfg<true, 8, 8, MODE>(n_wg, st, Q16, nqt, C16, N, d, 0, rows_per_wg, nullptr, nullptr, nullptr, 32 * nqb, tile_step, ta);
     }
     return fail(SDAG_ERR_ARG, "bad pass width");
 }
@@ -922,7 +1227,7 @@ extern "C" int sdag_dense_topk(const float* Q, int nq, const float* C, int64_t N
         const int nqt = nq - q0 < qtw ? nq - q0 : qtw;
         if (N > 0)
             if (int rc = launch_scan<false>(nqb, pl.n_wg, st, (const void*)(Q + (int64_t)q0 * d), nqt, (const void*)C, N, d, k,
-                                            pl.rows_per_wg, part_s, part_i, (const int*)nullptr, false))
+                                            pl.rows_per_wg, part_s, part_i, (const int*)nullptr, 0))
                 return rc;
         hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, part_s, part_i, N > 0 ? pl.n_wg : 0, nqt, qtw,
                            k, id_base, out_s + (int64_t)q0 * k, out_i + (int64_t)q0 * k, (const int*)nullptr);
@@ -947,23 +1252,70 @@ extern "C" int sdag_corpus_to_bf16(const float* C, int64_t N, int d, void* C16, 
 }
 
 namespace {
-struct Ws2 { int64_t part_s, part_i, flag, eps, q16, exact, rs, total; int n_flags, nqb; };
+// ---- plan of a two-stage search.  Up to 32 queries (or a small corpus): list scan + rescore_kernel, as described
+// above.  More queries: per pass of up to 256 queries a pilot (the list scan over every THR_STEP-th tile, keeping
+// the THR m best), the threshold scan, rescore_cand_kernel; the exact list scan stands by in sub-passes of 128.
+constexpr int THR_STEP = 32;            // the pilot scans one 128-row tile in THR_STEP
+constexpr int THR_MIN_TILES = 8;        // ... and needs at least this many (else: the list scan)
+constexpr int THR_CAP = RS_G * RS2_MAX; // candidates per query the global lists hold
+// Entries the pilot keeps per query: the number of rows of the whole corpus at or above the sample's m-th best score is
+// about THR_STEP times a Gamma(m) variate; it has to reach k for the candidate list to be vouched for, and with
+// m = 4 + ceil(k / 6) it fails to with a probability of some 1e-5 per query (k = 10: m = 6, 190 such rows expected).
+inline int pilot_m(int k) { return 4 + (k + 5) / 6; }
+
+struct Ws2 {
+    bool thr;            // threshold-scan path
+    int nqb, qtw;        // query blocks and queries per pass
+    int n_flags;         // passes
+    int m;               // the pilot's statistic: the m-th largest block maximum of the sample
+    int64_t bm_parts;    // block maxima per query in groups of m (the merge kernel's lists)
+    ScanPlan main, pilot, exact;  // stripes of the candidate scan, of the pilot, of the stand-by exact scan
+    int ex_nqb;          // query blocks of an exact sub-pass
+    int64_t part_s, part_i, flag, eps, q16, exact_l, rs, pil_s, pil_i, cand_s, cand_i, cand_n, total;
+};
 Ws2 plan_ws2(int nq, int64_t N, int d, int k) {
     const int ks = scan_keep(k);
-    Ws2 w;
-    w.nqb = pass_blocks(nq, ks);
-    const int qtw = QT * w.nqb;
-    const ScanPlan pl = plan_scan(N, w.nqb);
+    Ws2 w = {};
+    const int64_t tiles = (N + TR - 1) / TR;
+    const int64_t sampled = (tiles + THR_STEP - 1) / THR_STEP;
+    w.thr = nq > QT && sampled >= THR_MIN_TILES;
+    w.m = pilot_m(k);
+    if (w.thr && (((sampled * 4 + w.m - 1) / w.m * w.m + 63) / 64) * w.m > MRG_A) w.thr = false;  // too many block maxima to merge
+    if (w.thr) {
+        w.qtw = nq <= 64 ? 64 : nq <= 128 ? 128 : 256;
+        w.nqb = w.qtw / QT;
+        w.main = plan_scan(N, w.nqb);
+        w.pilot = plan_scan(sampled * TR, 2);  // (stripes over the sampled tiles)
+        w.bm_parts = (sampled * 4 + w.m - 1) / w.m;
+        w.ex_nqb = k > WIDE_KS ? 2 : (w.nqb < MAX_NQB ? w.nqb : MAX_NQB);
+        w.exact = plan_scan(N, w.ex_nqb);
+    } else {
+        w.nqb = pass_blocks(nq, ks);
+        w.qtw = QT * w.nqb;
+        w.main = plan_scan(N, w.nqb);
+        w.ex_nqb = w.nqb;
+        w.exact = w.main;
+    }
+    const int qtw = w.qtw;
     int64_t off = 0;
     auto take = [&](int64_t bytes) { const int64_t o = off; off += (bytes + 255) & ~255ll; return o; };
-    w.part_s = take((int64_t)pl.n_wg * qtw * ks * 4);
-    w.part_i = take((int64_t)pl.n_wg * qtw * ks * 4);
+    // stripe lists of the candidate list scan, or the pilot's block maxima
+    const int64_t list_entries = w.thr ? w.bm_parts * qtw * w.m : (int64_t)w.main.n_wg * qtw * ks;
+    w.part_s = take(list_entries * 4);
+    w.part_i = take(list_entries * 4);
     w.n_flags = (nq + qtw - 1) / qtw;  // one fallback flag per pass over the corpus
     w.flag = take((int64_t)(w.n_flags > 0 ? w.n_flags : 1) * 4);
     w.eps = take((int64_t)nq * 4);
     w.q16 = take((int64_t)w.n_flags * qtw * d * 2);  // whole passes (slab-major)
-    w.exact = take((int64_t)pl.n_wg * qtw * k * 8);
+    w.exact_l = take((int64_t)w.exact.n_wg * QT * w.ex_nqb * k * 8);
     w.rs = take((int64_t)RS_G * qtw * k * 8);  // the rescoring blocks' partial lists
+    if (w.thr) {
+        w.pil_s = take((int64_t)nq * w.m * 4);
+        w.pil_i = take((int64_t)nq * w.m * 8);
+        w.cand_s = take((int64_t)nq * THR_CAP * 4);
+        w.cand_i = take((int64_t)nq * THR_CAP * 4);
+        w.cand_n = take((int64_t)nq * 4);
+    }
     w.total = off;
     return w;
 }
@@ -992,8 +1344,7 @@ extern "C" int sdag_dense_topk2(const float* Q, int nq, const float* C, const vo
     if (((uintptr_t)Q | (uintptr_t)C | (uintptr_t)C16) & 15) return fail(SDAG_ERR_ARG, "Q, C and C16 must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const Ws2 w = plan_ws2(nq, N, d, k);
-    const int nqb = w.nqb, qtw = QT * nqb;
-    const ScanPlan pl = plan_scan(N, nqb);
+    const int nqb = w.nqb, qtw = w.qtw;
     if (!workspace || workspace_bytes < w.total) return fail(SDAG_ERR_CAPACITY, "workspace needs %lld bytes", (long long)w.total);
     unsigned char* ws = (unsigned char*)workspace;
     float* part_s = (float*)(ws + w.part_s);
@@ -1001,37 +1352,72 @@ extern "C" int sdag_dense_topk2(const float* Q, int nq, const float* C, const vo
     int* flags = (int*)(ws + w.flag);
     float* eps = (float*)(ws + w.eps);
     unsigned short* q16 = (unsigned short*)(ws + w.q16);
-    float* ex_s = (float*)(ws + w.exact);
-    int* ex_i = (int*)(ex_s + (int64_t)pl.n_wg * qtw * k);
+    const int ex_qtw = QT * w.ex_nqb;
+    float* ex_s = (float*)(ws + w.exact_l);
+    int* ex_i = (int*)(ex_s + (int64_t)w.exact.n_wg * ex_qtw * k);
     float* rs_s = (float*)(ws + w.rs);
     int* rs_i = (int*)(rs_s + (int64_t)RS_G * qtw * k);
     const int ks = scan_keep(k);
-    if ((((int64_t)pl.n_wg * k + 63) / 64) * k > MRG_A) return fail(SDAG_ERR_ARG, "too many partial lists for the merge");
-    hipLaunchKernelGGL(query_prepare_kernel, dim3(nq), dim3(256), 0, st, Q, d, max_row_norm, q16, eps, flags, w.n_flags, qtw);
+    if ((((int64_t)w.main.n_wg * k + 63) / 64) * k > MRG_A || (((int64_t)w.exact.n_wg * k + 63) / 64) * k > MRG_A)
+        return fail(SDAG_ERR_ARG, "too many partial lists for the merge");
+    int* cand_n = w.thr ? (int*)(ws + w.cand_n) : nullptr;
+    hipLaunchKernelGGL(query_prepare_kernel, dim3(nq), dim3(256), 0, st, Q, d, max_row_norm, q16, eps, flags, w.n_flags, qtw, cand_n);
     SDAG_HIP_CHECK(hipGetLastError());
     for (int q0 = 0; q0 < nq; q0 += qtw) {
         const int nqt = nq - q0 < qtw ? nq - q0 : qtw;
         float* os = out_s + (int64_t)q0 * k;
         int64_t* oi = out_i + (int64_t)q0 * k;
         int* flag = flags + q0 / qtw;
-        if (N > 0)
-            if (int rc = launch_scan<true>(nqb, pl.n_wg, st, (const void*)(q16 + (int64_t)q0 * d), nqt, C16, N, d, ks, pl.rows_per_wg,
-                                           part_s, part_i, (const int*)nullptr, true))
+        const unsigned short* q16p = q16 + (int64_t)q0 * d;  // this pass's slab-major block
+        if (w.thr) {
+            ThrArgs ta;
+            ta.pilot_s = (float*)(ws + w.pil_s) + (int64_t)q0 * w.m;
+            ta.pilot_i = (int64_t*)(ws + w.pil_i) + (int64_t)q0 * w.m;
+            ta.m = w.m;
+            ta.eps = eps + q0;
+            ta.cand_s = (float*)(ws + w.cand_s) + (int64_t)q0 * THR_CAP;
+            ta.cand_i = (int*)(ws + w.cand_i) + (int64_t)q0 * THR_CAP;
+            ta.cand_n = cand_n + q0;
+            ta.cap = THR_CAP;
+            ta.flag = flag;
+            // pilot: the largest approximate score of every 32-row block of one tile in THR_STEP, then the m-th largest of
+            // those per query
+            ta.bm_s = part_s;
+            ta.bm_i = part_i;
+            ta.bm_m = w.m;
+            ta.bm_qtw = qtw;
+            SDAG_HIP_CHECK(hipMemsetAsync(part_i, 0xff, (size_t)(w.bm_parts * qtw * w.m) * 4, st));  // -1: no entry
+            if (int rc = launch_thr_scan<MODE_BMAX>(nqb, w.pilot.n_wg, st, (const void*)q16p, nqt, C16, N, d, w.pilot.rows_per_wg, THR_STEP, ta))
                 return rc;
-        hipLaunchKernelGGL(rescore_kernel, dim3(RS_G, nqt), dim3(256), 0, st, Q + (int64_t)q0 * d, C, d, k, ks, part_s, part_i,
-                           N > 0 ? pl.n_wg : 0, qtw, eps + q0, rs_s, rs_i, flag);
-        SDAG_HIP_CHECK(hipGetLastError());
+            hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, part_s, part_i, (int)w.bm_parts, nqt, qtw, w.m,
+                               (int64_t)0, const_cast<float*>(ta.pilot_s), const_cast<int64_t*>(ta.pilot_i), (const int*)nullptr);
+            SDAG_HIP_CHECK(hipGetLastError());
+            if (int rc = launch_thr_scan<MODE_THR>(nqb, w.main.n_wg, st, (const void*)q16p, nqt, C16, N, d, w.main.rows_per_wg, 1, ta)) return rc;
+            hipLaunchKernelGGL(rescore_cand_kernel, dim3(RS_G, nqt), dim3(256), 0, st, Q + (int64_t)q0 * d, C, d, k, ta, qtw, rs_s, rs_i);
+            SDAG_HIP_CHECK(hipGetLastError());
+        } else {
+            if (N > 0)
+                if (int rc = launch_scan<true>(nqb, w.main.n_wg, st, (const void*)q16p, nqt, C16, N, d, ks, w.main.rows_per_wg, part_s,
+                                               part_i, (const int*)nullptr, qtw))
+                    return rc;
+            hipLaunchKernelGGL(rescore_kernel, dim3(RS_G, nqt), dim3(256), 0, st, Q + (int64_t)q0 * d, C, d, k, ks, part_s, part_i,
+                               N > 0 ? w.main.n_wg : 0, qtw, eps + q0, rs_s, rs_i, flag);
+            SDAG_HIP_CHECK(hipGetLastError());
+        }
         hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, rs_s, rs_i, RS_G, nqt, qtw, k, id_base, os, oi,
                            (const int*)nullptr);
         SDAG_HIP_CHECK(hipGetLastError());
         if (N > 0 && !SDAG_SCAN_EXP) {
             // only when the rescoring kernel could not vouch for its candidate set: the exact scan of the pass
-            if (int rc = launch_scan<false>(nqb, pl.n_wg, st, (const void*)(Q + (int64_t)q0 * d), nqt, (const void*)C, N, d, k,
-                                            pl.rows_per_wg, ex_s, ex_i, (const int*)flag, false))
-                return rc;
-            hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, ex_s, ex_i, pl.n_wg, nqt, qtw, k, id_base, os,
-                               oi, (const int*)flag);
-            SDAG_HIP_CHECK(hipGetLastError());
+            for (int s0 = 0; s0 < nqt; s0 += ex_qtw) {
+                const int nqs = nqt - s0 < ex_qtw ? nqt - s0 : ex_qtw;
+                if (int rc = launch_scan<false>(w.ex_nqb, w.exact.n_wg, st, (const void*)(Q + (int64_t)(q0 + s0) * d), nqs, (const void*)C,
+                                                N, d, k, w.exact.rows_per_wg, ex_s, ex_i, (const int*)flag, 0))
+                    return rc;
+                hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqs), dim3(MRG_THREADS), 0, st, ex_s, ex_i, w.exact.n_wg, nqs, ex_qtw, k,
+                                   id_base, os + (int64_t)s0 * k, oi + (int64_t)s0 * k, (const int*)flag);
+                SDAG_HIP_CHECK(hipGetLastError());
+            }
         }
     }
     return SDAG_OK;

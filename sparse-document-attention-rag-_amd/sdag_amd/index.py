@@ -169,7 +169,7 @@ class FlatIPIndex:
         return out_s, out_i
 
     def last_search_fell_back(self) -> bool:
-        """Diagnostics: did the last two-stage search (its last batch of 32 queries) have to run the exact scan?"""
+        """Diagnostics: did the last two-stage search (the last of its passes over the corpus) have to run the exact scan?"""
         if not self.two_stage or getattr(self, "_last", None) is None:
             return False
         nq, N, kk = self._last

@@ -131,6 +131,43 @@ def test_dense_topk_more_than_32_queries_per_pass(N, d, nq, k):
         assert np.array_equal(s32.view(np.uint32), s.view(np.uint32))
 
 
+def test_threshold_scan_on_hostile_corpora():
+    """More than 32 queries over a corpus large enough for the threshold scan (thresholds from a sample, every row at
+    or above them a candidate, exact rescoring of the ones near the k-th best): corpora built against it -- thousands of
+    rows within rounding distance of a query's best score (the candidate lists overflow), a block of exact duplicates
+    that the sample never sees (tiles the pilot skips), rows with wildly different norms, a query equal to a corpus row,
+    all-zero queries -- must still give the oracle's ids and score bits, through the exact scan where the candidate set
+    cannot be vouched for."""
+    import sdag_amd
+    from oracle import dense_ref
+
+    rng = np.random.default_rng(23)
+    d, nq, k, N = 128, 70, 10, 60000
+    Q = rng.standard_normal((nq, d), dtype=np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    fell = []
+    for case in range(3):
+        C = rng.standard_normal((N, d), dtype=np.float32)
+        C /= np.linalg.norm(C, axis=1, keepdims=True)
+        if case == 0:
+            C[130:160] = Q[1]                        # 30 exact duplicates inside a tile the pilot does not sample
+            C[40000] = Q[2]
+            Q[3] = C[777]
+        elif case == 1:
+            C[1000:7000] = Q[0] * 0.9 + 1e-4 * rng.standard_normal((6000, d), dtype=np.float32)   # 6000 near-ties
+        else:
+            C *= np.exp(rng.uniform(-5, 5, (N, 1))).astype(np.float32)
+            Q[5] = 0.0                               # every row scores 0: all of them are candidates
+        rs, ri = dense_ref.dense_topk(Q, C, k, id_base=3)
+        idx = sdag_amd.FlatIPIndex(d, device=_dev(), id_base=3)
+        idx.add(C)
+        s, i = idx.search(Q, k)
+        assert np.array_equal(i, ri), (case, np.argwhere(i != ri)[:5])
+        assert np.array_equal(s.view(np.uint32), rs.view(np.uint32)), case
+        fell.append(idx.last_search_fell_back())
+    assert not fell[0] and fell[1]            # the flood of near-ties is answered by the exact scan
+
+
 def test_two_stage_search_when_candidates_abound():
     """Corpora built against the candidate scan: hundreds of rows within rounding distance of the best score (more
     candidates than the rescoring kernel holds, and whole stripes full of them), exact duplicates, a corpus smaller
