@@ -218,6 +218,18 @@ int sdag_dense_topk(const float* Q, int nq, const float* C, int64_t N, int d, in
                     float* out_s, int64_t* out_i, int64_t id_base,
                     void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The next page of the same search: the best k rows among those that come strictly AFTER the entry
+ * (after_s[q], after_i[q]) of query q in the order of the results (after_s [nq] fp32, after_i [nq] int64 ids as
+ * returned, i.e. including id_base; both on the device).  With the last entry of the previous page as the cursor,
+ * successive calls return ranks k+1 .. 2k, 2k+1 .. 3k, ...: the reference's index.search(q, top_k)
+ * (src/pipeline/retrieval/dense.py:82-84) takes any top_k, one call here returns at most 32 entries per query.
+ * The cursor may name a row of another shard (the order is over global ids).  A cursor that is a fill entry
+ * (-FLT_MAX, -1) leaves nothing to return.  Same arguments and workspace as sdag_dense_topk otherwise. */
+int sdag_dense_topk_after(const float* Q, int nq, const float* C, int64_t N, int d, int k,
+                          const float* after_s, const int64_t* after_i,
+                          float* out_s, int64_t* out_i, int64_t id_base,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
 /* The same search, same results bit for bit, in two stages that read half the bytes: a scan over a bf16 copy of
  * the corpus picks candidates (every row whose approximate score is within a proven error bound of the k-th best),
  * which are then scored with the exact fp32 chain and ranked.  When the candidate set cannot be vouched for (more

@@ -138,6 +138,12 @@ struct ThrArgs {
     float* bm_s;
     int* bm_i;
     int bm_m, bm_qtw;
+    // exact list scan only (the other fields unused): a cursor per query.  Only rows that come strictly after
+    // (after_s[q], after_i[q] - after_base) in the order of the results are kept: the next page of a search whose
+    // previous page ended at that entry.  Null: no cursor.
+    const float* after_s;
+    const int64_t* after_i;
+    int64_t after_base;
 };
 
 // The threshold of a query in the threshold scan: the sample's m-th best approximate score less 2 eps (every row whose
@@ -391,6 +397,19 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW, MODE != 0>::WG_PER_CU)) 
     float* cs = reinterpret_cast<float*>(smem + OFF_CS);
     int* ci = reinterpret_cast<int*>(smem + OFF_CI);
     int* cnt = reinterpret_cast<int*>(smem + OFF_CNT);
+    // the cursors of this lane's queries (exact scan): every row is after (+inf, -1)
+    constexpr bool CURSOR = !BF16 && MODE == MODE_LISTS;
+    float cur_s[QPW];
+    int64_t cur_i[QPW];
+    if constexpr (CURSOR) {
+#pragma unroll
+        for (int qb = 0; qb < QPW; ++qb) {
+            const int qi = (qg * QPW + qb) * 32 + r;
+            const bool has = ta.after_s != nullptr && qi < nq;
+            cur_s[qb] = has ? ta.after_s[qi] : INFINITY;
+            cur_i[qb] = has ? ta.after_i[qi] - ta.after_base : -1;
+        }
+    }
     auto push_round = [&](int round_base, const int64_t row_base) {
 #pragma unroll
         for (int qb = 0; qb < QPW; ++qb) {
@@ -405,6 +424,7 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW, MODE != 0>::WG_PER_CU)) 
                 const float sc = acc[qb][i];
                 const int64_t row = row_base + (i & 3) + 8 * (i >> 2);
                 keep[e] = qi < nq && row < N && sc == sc && better(sc, (int)row, ts, ti);
+                if constexpr (CURSOR) keep[e] = keep[e] && better(cur_s[qb], cur_i[qb], sc, row);
                 n_keep += keep[e] ? 1 : 0;
             }
             if (n_keep) {
@@ -1174,8 +1194,7 @@ int launch_scan_cfg(int n_wg, hipStream_t st, const void* Q, int nqt, const void
 // One pass of the list scan over the corpus (or a sample of it) for nqt <= 32 nqb queries.
 template <bool BF16>
 int launch_scan(int nqb, int n_wg, hipStream_t st, const void* Q, int nqt, const void* C, int64_t N, int d, int k, int rows_per_wg,
-                float* part_s, int* part_i, const int* run_flag, int slab_width, int tile_step = 1) {
-    const ThrArgs none = {};
+                float* part_s, int* part_i, const int* run_flag, int slab_width, int tile_step = 1, const ThrArgs& none = ThrArgs{}) {
     switch (nqb) {
         case 1: return launch_scan_cfg<BF16, 1, 4, MODE_LISTS>(n_wg, st, Q, nqt, C, N, d, k, rows_per_wg, part_s, part_i, run_flag, slab_width, tile_step, none);
         case 2: return launch_scan_cfg<BF16, 2, 8, MODE_LISTS>(n_wg, st, Q, nqt, C, N, d, k, rows_per_wg, part_s, part_i, run_flag, slab_width, tile_step, none);
@@ -1205,9 +1224,10 @@ extern "C" int64_t sdag_dense_workspace_bytes(int nq, int64_t N, int d, int k) {
     return ((int64_t)pl.n_wg * QT * nqb * k * 8 + 255) & ~255ll;
 }
 
-extern "C" int sdag_dense_topk(const float* Q, int nq, const float* C, int64_t N, int d, int k,
-                               float* out_s, int64_t* out_i, int64_t id_base,
-                               void* workspace, int64_t workspace_bytes, void* stream) {
+namespace {
+// The exact scan + merge; after_s / after_i (both or neither): a cursor per query, see ThrArgs.
+int dense_topk_exact(const float* Q, int nq, const float* C, int64_t N, int d, int k, const float* after_s, const int64_t* after_i,
+                     float* out_s, int64_t* out_i, int64_t id_base, void* workspace, int64_t workspace_bytes, void* stream) {
     if (nq < 0 || N < 0) return fail(SDAG_ERR_ARG, "negative nq or N");
     if (d <= 0 || d % KC) return fail(SDAG_ERR_ARG, "d=%d must be a positive multiple of %d", d, KC);
     if (k <= 0 || k > MAX_K) return fail(SDAG_ERR_ARG, "k=%d outside [1, %d]", k, MAX_K);
@@ -1225,15 +1245,36 @@ extern "C" int sdag_dense_topk(const float* Q, int nq, const float* C, int64_t N
     if ((( (int64_t)pl.n_wg * k + 63) / 64) * k > MRG_A) return fail(SDAG_ERR_ARG, "too many partial lists for the merge");
     for (int q0 = 0; q0 < nq; q0 += qtw) {
         const int nqt = nq - q0 < qtw ? nq - q0 : qtw;
+        ThrArgs ta = {};
+        if (after_s) {
+            ta.after_s = after_s + q0;
+            ta.after_i = after_i + q0;
+            ta.after_base = id_base;
+        }
         if (N > 0)
             if (int rc = launch_scan<false>(nqb, pl.n_wg, st, (const void*)(Q + (int64_t)q0 * d), nqt, (const void*)C, N, d, k,
-                                            pl.rows_per_wg, part_s, part_i, (const int*)nullptr, 0))
+                                            pl.rows_per_wg, part_s, part_i, (const int*)nullptr, 0, 1, ta))
                 return rc;
         hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, part_s, part_i, N > 0 ? pl.n_wg : 0, nqt, qtw,
                            k, id_base, out_s + (int64_t)q0 * k, out_i + (int64_t)q0 * k, (const int*)nullptr);
         SDAG_HIP_CHECK(hipGetLastError());
     }
     return SDAG_OK;
+}
+}  // namespace
+
+extern "C" int sdag_dense_topk(const float* Q, int nq, const float* C, int64_t N, int d, int k,
+                               float* out_s, int64_t* out_i, int64_t id_base,
+                               void* workspace, int64_t workspace_bytes, void* stream) {
+    return dense_topk_exact(Q, nq, C, N, d, k, nullptr, nullptr, out_s, out_i, id_base, workspace, workspace_bytes, stream);
+}
+
+extern "C" int sdag_dense_topk_after(const float* Q, int nq, const float* C, int64_t N, int d, int k,
+                                     const float* after_s, const int64_t* after_i,
+                                     float* out_s, int64_t* out_i, int64_t id_base,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+    if (nq > 0 && (!after_s || !after_i)) return fail(SDAG_ERR_ARG, "NULL cursor");
+    return dense_topk_exact(Q, nq, C, N, d, k, after_s, after_i, out_s, out_i, id_base, workspace, workspace_bytes, stream);
 }
 
 extern "C" int sdag_corpus_to_bf16(const float* C, int64_t N, int d, void* C16, float* max_row_norm, void* stream) {

@@ -50,6 +50,7 @@ SIGNATURES = {
     "sdag_decode_attn_prealloc": (i32, [vp, vp, vp, vp] + [i64] * 10 + [i32] * 5 + [ctypes.c_float, vp, vp, i32, vp, i64, i32, vp]),
     "sdag_dense_workspace_bytes": (i64, [i32, i64, i32, i32]),
     "sdag_dense_topk": (i32, [vp, i32, vp, i64, i32, i32, vp, vp, i64, vp, i64, vp]),
+    "sdag_dense_topk_after": (i32, [vp, i32, vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, i64, vp]),
     "sdag_topk_merge": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     "sdag_corpus_to_bf16": (i32, [vp, i64, i32, vp, vp, vp]),
     "sdag_dense_topk2_workspace_bytes": (i64, [i32, i64, i32, i32]),

@@ -145,6 +145,8 @@ class BoundBatchAttention:
     def __init__(self, query, key, value, batch: BatchDescriptor, out: torch.Tensor, scaling: Optional[float] = None):
         B, Hq, L, D = query.shape
         Hkv = key.shape[1]
+        if not query.is_cuda:
+            raise RuntimeError("sdag_attention_batch runs on the GPU only (no CPU fallback)")
         if query.dtype != torch.bfloat16 or key.dtype != torch.bfloat16 or value.dtype != torch.bfloat16:
             raise TypeError("bf16 query/key/value expected")
         if query.stride(3) != 1 or key.stride(3) != 1 or value.stride(3) != 1 or out.stride(3) != 1:

@@ -85,7 +85,7 @@ def _additive_mask(desc: Descriptor, S: int, dtype, device) -> torch.Tensor:
 
 
 def _dense_mask_fallback(module, query, key, value, desc, dropout, scaling, **kwargs):
-    """Prefill under a descriptor (or a batch of them) on a model the kernel does not cover (head_dim other than 128,
+    """Prefill under a descriptor (or a batch of them) on a model the kernel does not cover (head_dim above 128,
     query heads not a multiple of key/value heads): SDPA under the dense mask expanded from the descriptor on the GPU."""
     from transformers.integrations.sdpa_attention import sdpa_attention_forward
 
@@ -115,15 +115,23 @@ def _masked_prefill(module, query, key, value, desc, dropout, scaling, **kwargs)
         raise RuntimeError(f"SDAG prefill: {Lq} tokens do not match the active descriptor (L = {desc.L})")
     if dropout:
         raise NotImplementedError("attention dropout is not supported by the SDAG kernel (inference only)")
-    if not (D == 128 and Hq % key.shape[1] == 0):  # (a CPU tensor: the kernel wrappers raise)
+    if not (D <= 128 and Hq % key.shape[1] == 0):  # (a CPU tensor: the kernel wrappers raise)
         return _dense_mask_fallback(module, query, key, value, desc, dropout, scaling, **kwargs)
     q, k, v = query, key, value
     if q.dtype != torch.bfloat16:
         q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+    if D < 128:
+        # narrower heads (64, 96, ...) run the 128-wide kernel on zero-padded copies: the padding adds nothing to a
+        # score and yields zero output columns, which are dropped; the softmax scale stays that of the true width
+        if scaling is None:
+            scaling = D ** -0.5
+        q, k, v = (torch.nn.functional.pad(t, (0, 128 - D)) for t in (q, k, v))
     if isinstance(desc, BatchDescriptor):
         out = sdag_attention_batch(q, k, v, desc, scaling=scaling, out_dtype=torch.bfloat16)
     else:
         out = sdag_attention(q, k, v, desc, scaling=scaling, out_dtype=torch.bfloat16)
+    if D < 128:
+        out = out[..., :D]
     return (out if out.dtype == query.dtype else out.to(query.dtype)), None
 
 

@@ -16,7 +16,25 @@ import torch
 
 from . import _lib
 
-MAX_K = 32
+MAX_K = 32  # entries per query one kernel call returns; larger k is answered page by page
+
+
+def _paged(first_page, next_page, k: int):
+    """Best k per query for any k: the first 32 from ``first_page(32)``, every further page of up to 32 from
+    ``next_page(kk, after_s, after_i)`` with the previous page's last entry as the cursor (the pages are disjoint and
+    consecutive in the (score desc, id asc) order, so their concatenation is the top k)."""
+    s, i = first_page(min(k, MAX_K))
+    pages_s, pages_i = [s], [i]
+    done = s.shape[1]
+    while done < k:
+        kk = min(MAX_K, k - done)
+        s, i = next_page(kk, pages_s[-1][:, -1].contiguous(), pages_i[-1][:, -1].contiguous())
+        pages_s.append(s)
+        pages_i.append(i)
+        done += kk
+    if len(pages_s) == 1:
+        return pages_s[0], pages_i[0]
+    return torch.cat(pages_s, dim=1), torch.cat(pages_i, dim=1)
 
 
 def _as_f32_2d(x, name: str) -> np.ndarray:
@@ -109,21 +127,26 @@ class FlatIPIndex:
 
     # ---- device-resident variant (no host round trip)
     def search_device(self, q: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Any k >= 1, like faiss: up to 32 entries per query come from one search, the rest page by page from the
+        exact scan with a cursor (``search_after``), one pass over the fp32 corpus per 32 further entries."""
+        q, k = self._check_query(q, k)
+        return _paged(lambda kk: self._search_page(q, kk), lambda kk, a_s, a_i: self.search_after(q, kk, a_s, a_i), k)
+
+    def _check_query(self, q: torch.Tensor, k: int):
         if q.dim() != 2 or q.shape[1] != self.d:
             raise ValueError(f"q must be [nq, {self.d}]")
         k = int(k)
         if k <= 0:
             raise ValueError("k must be positive")
-        q = q.to(self.device, dtype=torch.float32).contiguous()
+        return q.to(self.device, dtype=torch.float32).contiguous(), k
+
+    def _search_page(self, q: torch.Tensor, kk: int, after=None) -> Tuple[torch.Tensor, torch.Tensor]:
         nq = q.shape[0]
-        kk = min(k, MAX_K)
-        if k > MAX_K:
-            raise ValueError(f"k={k} above the supported maximum {MAX_K}")
         out_s = torch.empty((nq, kk), dtype=torch.float32, device=self.device)
         out_i = torch.empty((nq, kk), dtype=torch.int64, device=self.device)
         N = self.ntotal
         lib = _lib.lib()
-        if self.two_stage and N > 0:
+        if self.two_stage and N > 0 and after is None:
             return self._search_two_stage(q, nq, kk, out_s, out_i)
         need = lib.sdag_dense_workspace_bytes(nq, N, self.d, kk)
         if need < 0:
@@ -132,10 +155,28 @@ class FlatIPIndex:
             self._ws = torch.empty(max(int(need), 256), dtype=torch.uint8, device=self.device)
         cptr = self._corpus.data_ptr() if N else None
         with torch.cuda.device(self.device):
-            rc = lib.sdag_dense_topk(q.data_ptr(), nq, cptr, N, self.d, kk, out_s.data_ptr(), out_i.data_ptr(),
-                                     self.id_base, self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr(self.device))
+            if after is None:
+                rc = lib.sdag_dense_topk(q.data_ptr(), nq, cptr, N, self.d, kk, out_s.data_ptr(), out_i.data_ptr(),
+                                         self.id_base, self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr(self.device))
+            else:
+                rc = lib.sdag_dense_topk_after(q.data_ptr(), nq, cptr, N, self.d, kk, after[0].data_ptr(), after[1].data_ptr(),
+                                               out_s.data_ptr(), out_i.data_ptr(), self.id_base, self._ws.data_ptr(),
+                                               self._ws.numel(), _lib.stream_ptr(self.device))
         _lib.check(rc)
         return out_s, out_i
+
+    def search_after(self, q: torch.Tensor, k: int, after_s: torch.Tensor, after_i: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The best k <= 32 rows per query among those that come strictly after the entry (after_s[j], after_i[j]) in
+        the order of the results (ids as returned, i.e. global): the next page of a search that ended there."""
+        q, k = self._check_query(q, k)
+        if k > MAX_K:
+            raise ValueError(f"a page holds at most {MAX_K} entries")
+        nq = q.shape[0]
+        a_s = after_s.to(self.device, dtype=torch.float32).contiguous()
+        a_i = after_i.to(self.device, dtype=torch.int64).contiguous()
+        if a_s.shape != (nq,) or a_i.shape != (nq,):
+            raise ValueError("one cursor entry per query")
+        return self._search_page(q, k, (a_s, a_i))
 
 
     def prepare(self) -> None:
@@ -251,9 +292,14 @@ class ShardedFlatIPIndex:
             raise ValueError("more rows than this rank's shard holds")
 
     def search_device(self, q: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        s, i = self.local.search_device(q, k)
-        ps, pi = unpack_partial(gather_partials(pack_partial(s, i), self.group))
-        return merge_partial_topk(ps, pi, k)
+        """Any k >= 1.  Every page of up to 32 entries is one local search + one all-gather + one merge; the cursor of
+        the pages after the first is the GLOBAL last entry of the page before (the same on every rank)."""
+        def merged(local):
+            ps, pi = unpack_partial(gather_partials(pack_partial(*local), self.group))
+            return merge_partial_topk(ps, pi, local[0].shape[1])
+
+        return _paged(lambda kk: merged(self.local.search_device(q, kk)),
+                      lambda kk, a_s, a_i: merged(self.local.search_after(q, kk, a_s, a_i)), int(k))
 
     def search(self, q, k: int) -> Tuple[np.ndarray, np.ndarray]:
         qa = _as_f32_2d(q, "q")

@@ -443,7 +443,8 @@ def test_generate_through_hf_hook_matches_reference_greedy_text(SDAG, monkeypatc
 def test_hook_never_runs_a_prefill_unmasked_while_a_descriptor_is_active(monkeypatch):
     """The reference masks every prefill (SDAG.py:167-176).  While a descriptor (or a batch of them) is active, a
     call with more than one query row that does not fit it raises instead of reaching stock causal attention; a call
-    the kernel cannot cover (head_dim 64) is refused on the CPU and masked through SDPA on a GPU."""
+    the kernel cannot cover (head_dim 256) is refused on the CPU and masked through SDPA on a GPU; narrower heads (64)
+    go to the kernel zero-padded, which refuses CPU tensors as well."""
     import sdag_amd
     from sdag_amd import hf_attention
     import transformers.integrations.sdpa_attention as sdpa_mod
@@ -465,14 +466,16 @@ def test_hook_never_runs_a_prefill_unmasked_while_a_descriptor_is_active(monkeyp
         for q, k, v in (qkv(1, 39), qkv(1, 41), qkv(1, 8, S=48)):       # shorter, longer, a chunk over a cache
             with pytest.raises(RuntimeError, match="SDAG prefill"):
                 fwd(None, q, k, v, None, scaling=1.0)
-        with pytest.raises(RuntimeError, match="GPU only"):               # head_dim 64: the dense-mask route, never unmasked
-            fwd(None, *qkv(1, 40, D=64), None, scaling=1.0)
+        for D in (256, 64):                                               # the dense-mask route / the kernel: never unmasked
+            with pytest.raises(RuntimeError, match="GPU only"):
+                fwd(None, *qkv(1, 40, D=D), None, scaling=1.0)
     with hf_attention.active_descriptor(batch):
         for q, k, v in (qkv(1, 40), qkv(3, 40), qkv(2, 39), qkv(2, 6, S=46)):  # wrong batch, too short, chunked
             with pytest.raises(RuntimeError, match="SDAG prefill"):
                 fwd(None, q, k, v, None, scaling=1.0)
-        with pytest.raises(RuntimeError, match="GPU only"):
-            fwd(None, *qkv(2, 40, D=64), None, scaling=1.0)
+        for D in (256, 64):
+            with pytest.raises(RuntimeError, match="GPU only"):
+                fwd(None, *qkv(2, 40, D=D), None, scaling=1.0)
         with pytest.raises(NotImplementedError):
             fwd(None, *qkv(2, 40), None, dropout=0.1, scaling=1.0)
 

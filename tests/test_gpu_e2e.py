@@ -275,20 +275,18 @@ def test_attention_cfg4_benchmark_head_layout_batch():
         assert bool((o32[b, Lb:] == 7.0).all())
 
 
-def test_prefill_on_unsupported_head_dim_is_masked_not_causal():
-    """A model whose head_dim the kernel does not cover (64) under an active descriptor / batch of descriptors: the
-    hook runs SDPA under the dense mask expanded from the descriptor, never plain causal attention."""
+def test_prefill_on_other_head_dims_is_masked_not_causal(monkeypatch):
+    """Models whose head_dim is not 128, under an active descriptor / batch of descriptors.  Narrower heads (64, 96) run
+    the kernel on zero-padded copies -- no L x L mask is built, stock attention is never reached; wider ones (256) run
+    SDPA under the dense mask expanded from the descriptor.  Never plain causal attention."""
     import sdag_amd
+    import transformers.integrations.sdpa_attention as sdpa_mod
     from oracle import sdag_ref
     from sdag_amd import hf_attention
 
     spans, qa, L = synthetic_layout(7, [30, 18, 41], 1, 9)
     nbr = [[1], [2], []]
     spans2, qa2, L2 = synthetic_layout(5, [22, 35], 2, 6)
-    g = torch.Generator().manual_seed(64)
-    q = torch.randn(2, 4, L, 64, generator=g)
-    k = torch.randn(2, 2, L, 64, generator=g)
-    v = torch.randn(2, 2, L, 64, generator=g)
     d1 = sdag_amd.from_spans(L, 7, spans, qa, nbr)
     d2 = sdag_amd.from_spans(L2, 5, spans2, qa2, None)
     m1 = torch.from_numpy(sdag_ref.mask_from_spans(L, 7, spans, qa, nbr))
@@ -299,22 +297,45 @@ def test_prefill_on_unsupported_head_dim_is_masked_not_causal():
         is_causal = True
         training = False
 
-    with hf_attention.active_descriptor(d1):
-        o, _ = hf_attention.sdag_hip_attention_forward(Mod(), q[:1].to(DEV), k[:1].to(DEV), v[:1].to(DEV), None, scaling=0.125)
-    ref1 = sdag_ref.masked_attention(q[:1], k[:1], v[:1], m1, 0.125)
-    # rows that allow nothing are left out: what a fused SDPA kernel returns for a row masked with finfo.min everywhere
-    # is that kernel's business (the reference on this GPU would get the same), the isolation of the others is the point
-    r1, r2 = m1.any(1), m2.any(1)
-    assert _rel_err(o.cpu()[:, r1], ref1[:, r1]) <= 1e-4
-    causal = sdag_ref.masked_attention(q[:1], k[:1], v[:1], torch.ones(L, L).tril().bool(), 0.125)
-    assert _rel_err(causal[:, r1], ref1[:, r1]) > 1e-2        # the two differ, so the comparison above means something
-    with hf_attention.active_descriptor(sdag_amd.BatchDescriptor([d1, d2])):
-        ob, _ = hf_attention.sdag_hip_attention_forward(Mod(), q.to(DEV), k.to(DEV), v.to(DEV), None, scaling=0.125)
-    ob = ob.cpu()
-    assert _rel_err(ob[:1, r1], ref1[:, r1]) <= 1e-4
-    ref2 = sdag_ref.masked_attention(q[1:, :, :L2], k[1:, :, :L2], v[1:, :, :L2], m2, 0.125)
-    assert _rel_err(ob[1:, :L2][:, r2], ref2[:, r2]) <= 1e-4
-    assert bool(torch.isfinite(ob).all())
+    stock = sdpa_mod.sdpa_attention_forward
+    reached = []
+
+    def spy(*a, **kw):
+        reached.append(1)
+        return stock(*a, **kw)
+
+    monkeypatch.setattr(sdpa_mod, "sdpa_attention_forward", spy)
+    for D, tol in ((64, 1e-3), (96, 1e-3), (256, 1e-4)):
+        g = torch.Generator().manual_seed(D)
+        q = torch.randn(2, 4, L, D, generator=g)
+        k = torch.randn(2, 2, L, D, generator=g)
+        v = torch.randn(2, 2, L, D, generator=g)
+        scale = D ** -0.5
+        if D < 128:      # the kernel computes on bf16 operands: compare on what it sees
+            q, k, v = (t.to(torch.bfloat16).float() for t in (q, k, v))
+        reached.clear()
+        with hf_attention.active_descriptor(d1):
+            o, _ = hf_attention.sdag_hip_attention_forward(Mod(), q[:1].to(DEV), k[:1].to(DEV), v[:1].to(DEV), None,
+                                                           scaling=None if D == 64 else scale)
+        assert o.shape == (1, L, 4, D) and o.dtype == torch.float32
+        ref1 = sdag_ref.masked_attention(q[:1], k[:1], v[:1], m1, scale)
+        # wide heads: rows that allow nothing are left out -- what a fused SDPA kernel returns for a row masked with
+        # finfo.min everywhere is that kernel's business (the reference on this GPU would get the same); the kernel
+        # route returns the reference's mean of V for them, so there every row is compared (to bf16 output rounding)
+        r1 = m1.any(1) if D > 128 else torch.ones(L, dtype=torch.bool)
+        r2 = m2.any(1) if D > 128 else torch.ones(L2, dtype=torch.bool)
+        otol = tol if D > 128 else 6e-3          # the hook returns the kernel's bf16 output (2^-8 relative)
+        assert _rel_err(o.cpu()[:, r1], ref1[:, r1]) <= otol
+        causal = sdag_ref.masked_attention(q[:1], k[:1], v[:1], torch.ones(L, L).tril().bool(), scale)
+        assert _rel_err(causal[:, r1], ref1[:, r1]) > 5e-2        # the two differ, so the comparison above means something
+        with hf_attention.active_descriptor(sdag_amd.BatchDescriptor([d1, d2])):
+            ob, _ = hf_attention.sdag_hip_attention_forward(Mod(), q.to(DEV), k.to(DEV), v.to(DEV), None, scaling=scale)
+        ob = ob.cpu()
+        assert _rel_err(ob[:1, r1], ref1[:, r1]) <= otol
+        ref2 = sdag_ref.masked_attention(q[1:, :, :L2], k[1:, :, :L2], v[1:, :, :L2], m2, scale)
+        assert _rel_err(ob[1:, :L2][:, r2], ref2[:, r2]) <= otol
+        assert bool(torch.isfinite(ob).all())
+        assert bool(reached) == (D > 128)                          # stock attention only for the wide heads, and masked
 
 
 def test_pipeline_chain_sharded_hybrid_selection_generation():
@@ -448,6 +469,18 @@ def test_sharded_index_on_rccl_and_8_way_split_of_21m_corpus():
         assert torch.equal(i1, i0) and torch.equal(s1, s0)
         gs, gi = dense_ref.dense_topk(Qh, Csub.cpu().numpy(), k)
         assert np.array_equal(i1.cpu().numpy(), gi) and np.array_equal(s1.cpu().numpy().view(np.uint32), gs.view(np.uint32))
+        # more than 32 results per query: pages of 32 behind a global cursor, one gather + merge per page
+        s2, i2 = shd.search_device(Q, 40)
+        gs, gi = dense_ref.dense_topk(Qh, Csub.cpu().numpy(), 40)
+        assert np.array_equal(i2.cpu().numpy(), gi) and np.array_equal(s2.cpu().numpy().view(np.uint32), gs.view(np.uint32))
+        # the same second page from four shards of that corpus: the cursor is the GLOBAL 32nd entry on every shard
+        a_s, a_i = s2[:, 31].contiguous(), i2[:, 31].contiguous()
+        parts = []
+        for r in range(4):
+            lo, hi = sdag_amd.shard_bounds(Csub.shape[0], 4, r)
+            parts.append(sdag_amd.FlatIPIndex.from_tensor(Csub[lo:hi], id_base=lo).search_after(Q, 8, a_s, a_i))
+        ms, mi = sdag_amd.merge_partial_topk(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), 8)
+        assert torch.equal(mi, i2[:, 32:]) and torch.equal(ms, s2[:, 32:])
     finally:
         dist.destroy_process_group()
     del C

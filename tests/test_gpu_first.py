@@ -131,6 +131,42 @@ def test_dense_topk_more_than_32_queries_per_pass(N, d, nq, k):
         assert np.array_equal(s32.view(np.uint32), s.view(np.uint32))
 
 
+@pytest.mark.parametrize("N,d,nq,k", [(30000, 128, 9, 33), (20000, 64, 40, 64), (6000, 256, 32, 100), (50, 64, 5, 70),
+                                      (9000, 96, 70, 45)])
+def test_dense_topk_any_k_page_by_page(N, d, nq, k):
+    """faiss answers index.search(q, top_k) for any top_k (dense.py:82-84); one kernel call here returns 32 entries per
+    query, the rest comes page by page from the exact scan with the previous page's last entry as the cursor: ids and
+    score bits equal to the oracle's top k, across exact ties that straddle a page boundary, for a corpus smaller than
+    k (fill), and for a cursor given directly."""
+    import sdag_amd
+    from oracle import dense_ref
+
+    rng = np.random.default_rng(N + k)
+    C = rng.standard_normal((N, d), dtype=np.float32)
+    C /= np.linalg.norm(C, axis=1, keepdims=True)
+    Q = rng.standard_normal((nq, d), dtype=np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    if N >= 1000:
+        # query 0: rows 500..539 are 40 exact copies of one vector and its best matches -> ties across the 32 | 33 boundary
+        C[500:540] = Q[0]
+        C[N - 1] = Q[0]
+    rs, ri = dense_ref.dense_topk(Q, C, k, id_base=7)
+    for two_stage in (True, False):
+        idx = sdag_amd.FlatIPIndex(d, device=_dev(), id_base=7, two_stage=two_stage)
+        idx.add(C)
+        s, i = idx.search(Q, k)
+        assert s.shape == (nq, k) and i.shape == (nq, k)
+        assert np.array_equal(i, ri), (two_stage, np.argwhere(i != ri)[:5])
+        assert np.array_equal(s.view(np.uint32), rs.view(np.uint32)), two_stage
+    # a page from a cursor in the middle of the list: ranks 6 .. 6 + 20 after entry 5
+    if N >= 1000:
+        dev = _dev()
+        ps, pi = idx.search_after(torch.from_numpy(Q).to(dev), 20, torch.from_numpy(rs[:, 5].copy()).to(dev),
+                                  torch.from_numpy(ri[:, 5].copy()).to(dev))
+        assert np.array_equal(pi.cpu().numpy(), ri[:, 6:26])
+        assert np.array_equal(ps.cpu().numpy().view(np.uint32), rs[:, 6:26].view(np.uint32))
+
+
 def test_threshold_scan_on_hostile_corpora():
     """More than 32 queries over a corpus large enough for the threshold scan (thresholds from a sample, every row at
     or above them a candidate, exact rescoring of the ones near the k-th best): corpora built against it -- thousands of
