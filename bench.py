@@ -521,7 +521,8 @@ def main():
     if os.path.exists(tp):
         try:
             tj = json.load(open(tp))
-            traffic = tj.get("sdag_attn_main_bytes_per_launch_" + args.config)
+            # (the sharded-corpus workload launches the same 32-prompt attention as the default one)
+            traffic = tj.get("sdag_attn_main_bytes_per_launch_" + ("cfg3" if args.config == "cfg5" else args.config))
             traffic_source = tj.get("source")
         except Exception:
             traffic = None
