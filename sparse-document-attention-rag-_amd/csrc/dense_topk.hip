@@ -1294,8 +1294,9 @@ extern "C" int sdag_corpus_to_bf16(const float* C, int64_t N, int d, void* C16, 
 
 namespace {
 // ---- plan of a two-stage search.  Up to 32 queries (or a small corpus): list scan + rescore_kernel, as described
-// above.  More queries: per pass of up to 256 queries a pilot (the list scan over every THR_STEP-th tile, keeping
-// the THR m best), the threshold scan, rescore_cand_kernel; the exact list scan stands by in sub-passes of 128.
+// above.  More queries: per pass of up to 256 queries a pilot (the block maxima of every THR_STEP-th tile, of which the
+// merge kernel keeps the m best per query), the threshold scan, rescore_cand_kernel; the exact list scan stands by in
+// sub-passes of up to 128.
 constexpr int THR_STEP = 32;            // the pilot scans one 128-row tile in THR_STEP
 constexpr int THR_MIN_TILES = 8;        // ... and needs at least this many (else: the list scan)
 constexpr int THR_CAP = RS_G * RS2_MAX; // candidates per query the global lists hold
@@ -1411,7 +1412,7 @@ extern "C" int sdag_dense_topk2(const float* Q, int nq, const float* C, const vo
         int* flag = flags + q0 / qtw;
         const unsigned short* q16p = q16 + (int64_t)q0 * d;  // this pass's slab-major block
         if (w.thr) {
-            ThrArgs ta;
+            ThrArgs ta = {};
             ta.pilot_s = (float*)(ws + w.pil_s) + (int64_t)q0 * w.m;
             ta.pilot_i = (int64_t*)(ws + w.pil_i) + (int64_t)q0 * w.m;
             ta.m = w.m;
