@@ -42,6 +42,33 @@ def _worker(rank, world, port, n_total, d, nq, k, q):
         ms, mi = dense_ref.merge_topk(ps.numpy(), pi.numpy(), k)
         gs, gi = dense_ref.dense_topk(Q, C, k)
         ok = np.array_equal(mi, gi) and np.array_equal(ms.view(np.uint32), gs.view(np.uint32))
+        # more than 32 results per query: the index's paging driver with the oracle standing in for the local searches;
+        # every page is one gather + merge, the cursor of the pages after the first is the GLOBAL last entry
+        from sdag_amd.index import _paged
+
+        sc = dense_ref.dense_scores(Q, C[lo:hi])                         # [rows, nq]
+        ids = np.arange(lo, hi, dtype=np.int64)
+
+        def local_after(kk, a_s, a_i):                                   # stands in for FlatIPIndex.search_after
+            out_s = np.full((nq, kk), -np.finfo(np.float32).max, dtype=np.float32)
+            out_i = np.full((nq, kk), -1, dtype=np.int64)
+            for j in range(nq):
+                keep = (sc[:, j] < a_s[j]) | ((sc[:, j] == a_s[j]) & (ids > a_i[j]))
+                order = np.lexsort((ids[keep], -sc[keep, j]))[:kk]
+                out_s[j, :len(order)] = sc[keep, j][order]
+                out_i[j, :len(order)] = ids[keep][order]
+            return torch.from_numpy(out_s), torch.from_numpy(out_i)
+
+        def merged(local):
+            gs_, gi_ = unpack_partial(gather_partials(pack_partial(*local)))
+            m_s, m_i = dense_ref.merge_topk(gs_.numpy(), gi_.numpy(), local[0].shape[1])
+            return torch.from_numpy(m_s), torch.from_numpy(m_i)
+
+        k_big = 40
+        ps_, pi_ = _paged(lambda kk: merged(tuple(torch.from_numpy(x) for x in dense_ref.dense_topk(Q, C[lo:hi], kk, id_base=lo))),
+                          lambda kk, a_s, a_i: merged(local_after(kk, a_s.numpy(), a_i.numpy())), k_big)
+        bs, bi = dense_ref.dense_topk(Q, C, k_big)
+        ok = ok and np.array_equal(pi_.numpy(), bi) and np.array_equal(ps_.numpy().view(np.uint32), bs.view(np.uint32))
         q.put((rank, bool(ok), (lo, hi)))
     finally:
         dist.destroy_process_group()
