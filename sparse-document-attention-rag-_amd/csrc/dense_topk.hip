@@ -57,7 +57,8 @@ constexpr int MAX_K = 32;
 constexpr int MAX_WG = 512;                 // stripe lists the merge and rescoring kernels can take
 constexpr int SCAN_WG = 256 * SDAG_SCAN_WG_PER_CU;  // workgroups of the narrow scan: what the chip holds at once
 #ifndef SDAG_SCAN_EXP
-#define SDAG_SCAN_EXP 0   // timing-only builds: 1 no filtering, 2 no MFMAs, 4 no query pieces, 8 no corpus pieces
+#define SDAG_SCAN_EXP 0   // timing-only builds: 1 no filtering (the MFMAs go with it: nothing reads the sums), 2 no MFMAs,
+                          // 4 no query pieces, 8 no corpus pieces, 16 no row passes the thresholds, 32 MFMA operands not read
 #endif
 constexpr int MAX_NQB = 4;                  // query blocks of the widest scan
 constexpr int WIDE_KS = 16;                 // longest stripe list the widest scan keeps (its lists are shorter: LDS)
@@ -68,6 +69,9 @@ constexpr int WIDE_KS = 16;                 // longest stripe list the widest sc
 #define SDAG_SCAN_QDMA 1   // 1: the wide scans bring their query slabs by LDS-DMA as well (waves 4-7), 0: through registers
 #endif
 #define SDAG_SCAN_NSTQ 2
+#ifndef SDAG_SCAN_QMID
+#define SDAG_SCAN_QMID 2   // the MFMA group (of four) of a pair of stages in front of which waves 4-7 issue the next slab (0: at the barrier)
+#endif
 static_assert(SCAN_WG <= MAX_WG, "the rescoring kernel holds one maximum per stripe in MAX_WG / 64 registers");
 static_assert(MAX_WG % 64 == 0, "stripe maxima are held 64 per register");
 
@@ -252,7 +256,14 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW, MODE != 0>::WG_PER_CU)) 
     const int64_t n_sampled = ((N + TR - 1) / TR + tile_step - 1) / tile_step;
     const int ntile = (int)max((int64_t)0, min((int64_t)(rows_per_wg / TR), n_sampled - tile0));
     const int nkc = d / KCE;
-    const int S = ntile * nkc;
+    // The threshold scan multiplies TWO consecutive corpus tiles against every query slab it stages (accumulators for
+    // both): the slab's pieces are then a third of what a pair of tiles brings into the LDS instead of two thirds of
+    // what one does, and the scan's time follows the pieces.  Corpus stage s is tile TPS * (s / (TPS nkc)) + s % TPS,
+    // dimensions block (s % (TPS nkc)) / TPS; query stage sq = s / TPS.  (An odd last tile has a phantom partner:
+    // loaded and multiplied like any other, never filtered.)
+    constexpr int TPS = MODE == MODE_THR ? 2 : 1;
+    const int S = ((ntile + TPS - 1) / TPS) * TPS * nkc;
+    const int SQ = S / TPS;
     auto tile_row0 = [&](int tile) { return (tile0 + tile) * tile_step * TR; };
 
     if constexpr (MODE != MODE_LISTS) {
@@ -281,7 +292,8 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW, MODE != 0>::WG_PER_CU)) 
     auto issue_c = [&](int s, int c) {  // corpus piece c of stage s
         if (SDAG_SCAN_EXP & 8) return;
         s = s < S ? s : S - 1;  // past the end: reload the last stage into the free slot (keeps vmcnt counts fixed)
-        const int tile = s / nkc, kc = s - tile * nkc;
+        const int grp = s / (TPS * nkc), within = s - grp * (TPS * nkc);
+        const int tile = grp * TPS + within % TPS, kc = within / TPS;
         unsigned char* sb = smem + (s % CFG::NSTC) * CFG::C_STRIDE;
         const int rl = c * 8 + dr;  // row inside the tile (the swizzle only looks at its low bits)
         int64_t row = tile_row0(tile) + rl;
@@ -290,9 +302,9 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW, MODE != 0>::WG_PER_CU)) 
         const unsigned char* src = C + (row * d + kc * KCE) * ES + csrc * 16;
         __builtin_amdgcn_global_load_lds(SDAG_GLB_PTR(src), SDAG_LDS_PTR(sb + c * 1024), 16, 0, 0);
     };
-    auto issue_q = [&](int s, int c) {  // query piece c of stage s
+    auto issue_q = [&](int s, int c) {  // query piece c of query stage s
         if (SDAG_SCAN_EXP & 4) return;
-        s = s < S ? s : S - 1;
+        s = s < SQ ? s : SQ - 1;
         const int kc = s % nkc;
         unsigned char* sb = smem + CFG::Q_BASE + (s % CFG::NSTQ) * CFG::Q_STRIDE;
         int j = c * 8 + dr;
@@ -317,7 +329,7 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW, MODE != 0>::WG_PER_CU)) 
     u32x4 qreg[CFG::PPW_Q];
     auto load_queries = [&](int s) {
         if (SDAG_SCAN_EXP & 4) return;
-        s = s < S ? s : S - 1;
+        s = s < SQ ? s : SQ - 1;
         const int kc = s % nkc;
 #pragma unroll
         for (int n = 0; n < CFG::PPW_Q; ++n) {
@@ -338,16 +350,19 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW, MODE != 0>::WG_PER_CU)) 
     const int a_off = (rg * 32 + r) * 128;
     const int b_off = (qg * QPW * 32 + r) * 128;
 
-    f32x16 acc[QPW];
+    f32x16 accs[TPS][QPW];
+    f32x16 (&acc)[QPW] = accs[0];  // (the scans of one tile per slab)
     float thr[QPW];  // threshold scan: this lane's queries' thresholds
 #pragma unroll
     for (int qb = 0; qb < QPW; ++qb) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[qb][i] = 0.f;
+        for (int hh = 0; hh < TPS; ++hh)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accs[hh][qb][i] = 0.f;
         thr[qb] = 0.f;
         if constexpr (THR) {
             const int qi = (qg * QPW + qb) * 32 + r;
-            thr[qb] = qi < nq ? thr_of(ta, qi) : INFINITY;
+            thr[qb] = qi < nq && !(SDAG_SCAN_EXP & 16) ? thr_of(ta, qi) : INFINITY;
         }
     }
     // Threshold scan: the workgroup's buffered survivors go to the queries' global lists (every thread takes some; the
@@ -370,10 +385,14 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW, MODE != 0>::WG_PER_CU)) 
         lds_barrier();
     };
 
+    // corpus stages a loading wave runs ahead of the MFMAs: all but one slot of the ring; with two tiles per slab the
+    // ring holds the pair that is computed and the pair that is loaded
+    constexpr int LOOK_C = TPS == 2 ? 2 : CFG::NSTC - 1;
+    static_assert(TPS == 1 || CFG::NSTC == 4, "two tiles per slab: a ring of two pairs");
     if constexpr (CFG::SPLIT) {
         if (w < 4) {
 #pragma unroll
-            for (int s0 = 0; s0 < CFG::NSTC - 1; ++s0) issue_corpus(s0);
+            for (int s0 = 0; s0 < LOOK_C; ++s0) issue_corpus(s0);
         } else if (SDAG_SCAN_QDMA) {
 #pragma unroll
             for (int s0 = 0; s0 < CFG::NSTQ - 1; ++s0) issue_queries(s0);
@@ -452,44 +471,66 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW, MODE != 0>::WG_PER_CU)) 
     };
 
     int tile = 0, kc = 0;
-    for (int s = 0; s < S; ++s) {
-        // stage s landed for this wave (the pieces of the newer stages may still fly), then for every wave
+    for (int s = 0; s < S; s += TPS) {
+        // stage s (TPS = 2: stages s and s + 1, and with them everything this wave has in flight) landed for this wave
+        // (the pieces of the newer stages may still fly), then for every wave
         if constexpr (CFG::SPLIT) {
             if (w < 4) {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(CFG::WAIT_C) : "memory");
-                issue_corpus(s + CFG::NSTC - 1);
+                // (the next pieces right behind the barrier: spread between the MFMAs below they land too late for
+                // the next stage's wait -- measured 20 % slower)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(TPS == 2 ? 0 : CFG::WAIT_C) : "memory");
+#pragma unroll
+                for (int hh = 0; hh < TPS; ++hh) issue_corpus(s + hh + LOOK_C);
             } else if (SDAG_SCAN_QDMA) {
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(CFG::PPW_Q * (CFG::NSTQ - 2)) : "memory");
-                issue_queries(s + CFG::NSTQ - 1);
+                if (TPS == 1 || !(SDAG_SCAN_QMID && NQB == 8)) issue_queries(s / TPS + CFG::NSTQ - 1);
             } else {
+                static_assert(SDAG_SCAN_QDMA || TPS == 1, "query slabs through registers: one tile per slab");
                 lds_barrier();  // (this wave's slab of stage s was written at the end of stage s - 1)
                 load_queries(s + 1);
             }
         } else {
+            static_assert(CFG::SPLIT || TPS == 1, "two tiles per slab: the scans with separate rings");
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(CFG::WAIT_C) : "memory");
             issue_corpus(s + NST - 1);
             issue_queries(s + NST - 1);
         }
         if constexpr (THR) {
-            // between a stage's barrier and a tile's end nobody appends: every wave reads the same count here
+            // between a stage's barrier and the tiles' end nobody appends: every wave reads the same count here
             if (kc == 0 && __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + CFG::OFF_BN)) > THR_CB / 2)
                 flush_buffer();
         }
-        const unsigned char* sbc = smem + (s % CFG::NSTC) * CFG::C_STRIDE;
-        const unsigned char* sbq = smem + CFG::Q_BASE + (s % CFG::NSTQ) * CFG::Q_STRIDE;
+        const unsigned char* sbc[TPS];
+#pragma unroll
+        for (int hh = 0; hh < TPS; ++hh) sbc[hh] = smem + ((s + hh) % CFG::NSTC) * CFG::C_STRIDE;
+        const unsigned char* sbq = smem + CFG::Q_BASE + ((s / TPS) % CFG::NSTQ) * CFG::Q_STRIDE;
 #pragma unroll
         for (int m = 0; m < ((SDAG_SCAN_EXP & 2) ? 0 : 4); ++m) {
+            if constexpr (TPS == 2 && SDAG_SCAN_QMID && NQB == 8 && CFG::SPLIT) {
+                // The waves that bring the query slabs issue their pieces in the middle of their MFMAs: right behind
+                // the barrier the SIMD's other wave is issuing corpus pieces, and the matrix pipe would idle.
+                if (m == SDAG_SCAN_QMID) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (w >= 4) issue_queries(s / TPS + CFG::NSTQ - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             const int ch = ((2 * m + h) ^ swz) << 4;
             if constexpr (BF16) {
-                // 16-byte chunk 2 m + h of a row = dimensions 16 m + 8 h .. + 7 of the stage: the MFMA operand as it is
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sbc + a_off + ch);
+                // 16-byte chunk 2 m + h of a row = dimensions 16 m + 8 h .. + 7 of the stage: the MFMA operand as it is;
+                // every query operand read from the LDS serves the TPS corpus tiles of the stage
+                bf16x8 a[TPS];
+#pragma unroll
+                for (int hh = 0; hh < TPS; ++hh) a[hh] = *reinterpret_cast<const bf16x8*>((SDAG_SCAN_EXP & 32) ? smem + a_off : sbc[hh] + a_off + ch);
 #pragma unroll
                 for (int qb = 0; qb < QPW; ++qb) {
-                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(sbq + b_off + qb * Q_STAGE + ch);
-                    acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[qb], 0, 0, 0);
+                    bf16x8 b;
+                    if (SDAG_SCAN_EXP & 32) b = a[0]; else b = *reinterpret_cast<const bf16x8*>(sbq + b_off + qb * Q_STAGE + ch);
+#pragma unroll
+                    for (int hh = 0; hh < TPS; ++hh) accs[hh][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[hh], b, accs[hh][qb], 0, 0, 0);
                 }
             } else {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(sbc + a_off + ch);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(sbc[0] + a_off + ch);
                 // Lane half 0 holds dimensions 8m..8m+3, half 1 holds 8m+4..8m+7.  Swapping the upper half of
                 // register 0 with the lower half of register 1 (and 2 with 3) leaves register 0 = (8m, 8m+1),
                 // register 2 = (8m+2, 8m+3), register 1 = (8m+4, 8m+5), register 3 = (8m+6, 8m+7) across the
@@ -514,9 +555,8 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW, MODE != 0>::WG_PER_CU)) 
             if (w >= 4) store_queries(s + 1);  // slab of stage s - 1: every wave passed this stage's barrier after reading it
         if (++kc < nkc) continue;
         kc = 0;
-        // ---- tile finished
+        // ---- tile(s) finished
         const int64_t row_base = tile_row0(tile) + rg * 32 + 4 * h;
-        ++tile;
         if constexpr (MODE == MODE_BMAX) {
 #pragma unroll
             for (int qb = 0; qb < QPW; ++qb) {
@@ -528,7 +568,7 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW, MODE != 0>::WG_PER_CU)) 
                 mx = fmaxf(mx, other);
                 const int qi = (qg * QPW + qb) * 32 + r;
                 if (h == 0 && qi < nq) {
-                    const int64_t e = (tile0 + tile - 1) * 4 + rg;  // (tile was advanced)
+                    const int64_t e = (tile0 + tile) * 4 + rg;
                     const int64_t at = ((e / ta.bm_m) * ta.bm_qtw + qi) * ta.bm_m + e % ta.bm_m;
                     ta.bm_s[at] = mx;
                     ta.bm_i[at] = (int)e;
@@ -536,27 +576,34 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW, MODE != 0>::WG_PER_CU)) 
             }
         } else if constexpr (THR) {
             if (!(SDAG_SCAN_EXP & 1)) {
-                bool mine = false;
 #pragma unroll
-                for (int qb = 0; qb < QPW; ++qb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) mine |= acc[qb][i] >= thr[qb] && row_base + (i & 3) + 8 * (i >> 2) < N;
-                if (__builtin_amdgcn_ballot_w64(mine) != 0) {
+                for (int hh = 0; hh < TPS; ++hh) {
+                    if (tile + hh >= ntile) break;  // the phantom partner of an odd last tile
+                    const int64_t rb = tile_row0(tile + hh) + rg * 32 + 4 * h;
+                    // Survivors are rare (about one per wave and pair of tiles): each block of 32 rows x 32 queries is
+                    // tested on its own, and only a block that holds one walks its sixteen registers lane by lane.
+                    // Rows past the corpus' end exist in its last tile only (their scores repeat the last row's).
+                    const bool whole = tile_row0(tile + hh) + TR <= N;
                     int* bn = reinterpret_cast<int*>(smem + CFG::OFF_BN);
 #pragma unroll
-                    for (int qb = 0; qb < QPW; ++qb)
+                    for (int qb = 0; qb < QPW; ++qb) {
+                        bool mine = false;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) mine |= accs[hh][qb][i] >= thr[qb];
+                        if (__builtin_amdgcn_ballot_w64(mine) == 0) continue;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
-                            const int64_t row = row_base + (i & 3) + 8 * (i >> 2);
-                            if (acc[qb][i] >= thr[qb] && row < N) {  // (a score that is not a number fails the test)
+                            const int64_t row = rb + (i & 3) + 8 * (i >> 2);
+                            if (accs[hh][qb][i] >= thr[qb] && (whole || row < N)) {  // (a score that is not a number fails the test)
                                 const int pos = atomicAdd(bn, 1);
                                 if (pos < THR_CB) {
                                     reinterpret_cast<int*>(smem + CFG::OFF_BQ)[pos] = (qg * QPW + qb) * 32 + r;
-                                    reinterpret_cast<float*>(smem + CFG::OFF_BS)[pos] = acc[qb][i];
+                                    reinterpret_cast<float*>(smem + CFG::OFF_BS)[pos] = accs[hh][qb][i];
                                     reinterpret_cast<int*>(smem + CFG::OFF_BI)[pos] = (int)row;
                                 }
                             }
                         }
+                    }
                 }
             }
         } else if (!(SDAG_SCAN_EXP & 1)) {
@@ -568,10 +615,13 @@ __global__ __launch_bounds__(64 * NW, (ScanCfg<NQB, NW, MODE != 0>::WG_PER_CU)) 
                 lds_barrier();
             }
         }
+        tile += TPS;
 #pragma unroll
-        for (int qb = 0; qb < QPW; ++qb)
+        for (int hh = 0; hh < TPS; ++hh)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[qb][i] = 0.f;
+            for (int qb = 0; qb < QPW; ++qb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) accs[hh][qb][i] = 0.f;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();

@@ -13,7 +13,7 @@ C = torch.empty((N, d), device=dev)
 for lo in range(0, N, 1 << 18):
     x = torch.randn((min(N, lo + (1 << 18)) - lo, d), device=dev); C[lo:lo + x.shape[0]] = x / x.norm(dim=1, keepdim=True)
 idx = sdag_amd.FlatIPIndex(d, device=dev, two_stage="exact" not in sys.argv); idx._corpus = C
-for nq in ((32, 64, 100, 128, 256, 1024) if "wide" in sys.argv else (32, 64)):
+for nq in ((256,) if "only256" in sys.argv else (128,) if "only128" in sys.argv else (32, 64, 100, 128, 256, 1024) if "wide" in sys.argv else (32, 64)):
     Q = torch.randn((nq, d), device=dev); Q = Q / Q.norm(dim=1, keepdim=True)
     idx.search_device(Q, K); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
