@@ -22,6 +22,13 @@
 // filtered against a per-query threshold (the current k-th best of the stripe) and survivors are appended to
 // per-query candidate lists in LDS, which are compacted to their best k whenever they could overflow.
 // Each workgroup finally writes its best k per query; a merge kernel reduces those lists.
+//
+// The same kernel template has a bf16 form (a bf16 copy of the corpus, one v_mfma_f32_32x32x16_bf16 per 16
+// dimensions) that only picks candidates for exact rescoring (sdag_dense_topk2: same results bit for bit, half the
+// bytes), and for more than 32 queries a threshold form (up to 256 queries per pass, two corpus tiles per staged query
+// slab, no lists: every row at or above a per-query threshold taken from a pilot over a sample goes to that query's
+// candidate list in global memory); see dense_scan.  sdag_dense_topk_after is the exact scan behind a cursor (paging
+// for k above 32).
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
