@@ -225,9 +225,12 @@ int main(int argc, char** argv) {
             const int32_t* d = t + t[t[BT_OFF_DESC] + b];
             CHECK(desc_ok(d) && st[S_L] == d[H_L], "step descriptor");
             CHECK(std::memcmp(d, ptrs[(size_t)b], sizeof(int32_t) * (size_t)d[H_OFF_STEPS]) == 0, "descriptor copy");
-            if (st[S_MOFF]) {
-                const int64_t lo = (int64_t)t[t[BT_OFF_DESC] + b] + d[H_OFF_LMASKS];
-                CHECK(st[S_MOFF] >= lo && st[S_MOFF] + 64 <= lo + (int64_t)d[H_NMASKS] * 64 && st[S_MOFF] + 64 <= need, "batch mask offset");
+            if (st[S_MOFF]) {  // inside the table, at a 64-byte boundary, and one of the sequence's lane masks word for word
+                CHECK(st[S_MOFF] > 0 && st[S_MOFF] % 16 == 0 && st[S_MOFF] + 64 <= need, "batch mask offset");
+                const int32_t* lm = d + d[H_OFF_LMASKS];
+                bool is_one = false;
+                for (int m = 0; m < d[H_NMASKS] && !is_one; ++m) is_one = std::memcmp(t + st[S_MOFF], lm + (size_t)m * 64, 256) == 0;
+                CHECK(is_one, "batch mask contents");
             }
             ++per_seq[(size_t)b];
         }

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstring>
 #include <functional>
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -45,6 +46,7 @@ struct SchedUnit {
     int32_t b, row0, item_begin, item_end, slot, ubits, L;
     const int32_t* items;  // the sequence's {first key, mask index} pairs
     int64_t lmask_base;    // word offset (from the start of the table the steps live in) of that sequence's lane masks
+    const int32_t* lmask_at = nullptr;  // or: word offset of every lane mask of the sequence (a pool shared by a batch)
 };
 
 // Cost of a unit in quarter steps: loading its Q rows and storing its O rows takes about as long as 1.25 tile steps
@@ -109,7 +111,7 @@ void build_schedule(const std::vector<SchedUnit>& units, int n_streams, int32_t*
                 int32_t* w = steps + n * STEP_WORDS;
                 const int32_t mi = u.items[2 * it + 1];
                 w[S_KEY0] = u.items[2 * it];
-                w[S_MOFF] = mi < 0 ? 0 : (int32_t)(u.lmask_base + (int64_t)mi * 64);
+                w[S_MOFF] = mi < 0 ? 0 : u.lmask_at ? u.lmask_at[mi] : (int32_t)(u.lmask_base + (int64_t)mi * 64);
                 w[S_FLAGS] = (it == u.item_begin ? 1 : 0) | (it + 1 == u.item_end ? 2 : 0);
                 w[S_B] = u.b;
                 w[S_L] = u.L;
@@ -183,12 +185,19 @@ int emit(int L, std::vector<int> cuts, const FillFn& fill, int max_items_per_uni
     const int nrb = (int)rb_row0.size();
     auto rb_rows = [&](int rb) { return (rb + 1 < nrb ? rb_row0[rb + 1] : L) - rb_row0[rb]; };
 
-    std::vector<uint64_t> bits((size_t)RB * std::max(nw, 1), 0ull), uni_cols((size_t)std::max(nw, 1), 0ull);
+    // uni_cols / all_cols: per 64-bit word of the block's rows, the keys SOME row / EVERY row may attend
+    std::vector<uint64_t> bits((size_t)RB * std::max(nw, 1), 0ull), uni_cols((size_t)std::max(nw, 1), 0ull),
+        all_cols((size_t)std::max(nw, 1), 0ull);
     std::vector<uint8_t> touched((size_t)std::max(nw, 1), 0);
     std::vector<int32_t> tw;               // the touched word indices of the current block
     std::vector<int32_t> items;            // {key0, mask}
     std::vector<int32_t> rb_item_begin(nrb + 1, 0);
-    std::vector<uint64_t> masks;           // 32 words per mask
+    std::vector<uint64_t> masks;           // 32 words per mask; equal masks are stored once
+    // Tiles follow the documents, so the staircase of one document's triangle repeats in every other document: a prompt
+    // of ten like documents has a tenth of the distinct masks (less to build, to upload and to pull through the GPU's
+    // scalar cache).  hash of a mask -> index of the first mask with that hash, chained through `next_same`.
+    std::unordered_map<uint64_t, int32_t> mask_of;
+    std::vector<int32_t> next_same;
     std::vector<int32_t> rbinfo((size_t)nrb * 2, 0);
     std::vector<int32_t> uniform;
     int64_t pairs = 0;
@@ -208,6 +217,7 @@ int emit(int L, std::vector<int> cuts, const FillFn& fill, int max_items_per_uni
                 const uint64_t w = row[t];
                 any |= w;
                 uni_cols[t] |= w;
+                all_cols[t] = r == 0 ? w : all_cols[t] & w;
                 pairs += __builtin_popcountll(w);
             }
             if (!any) {
@@ -224,14 +234,30 @@ int emit(int L, std::vector<int> cuts, const FillFn& fill, int max_items_per_uni
             while (!w && ++t < nw) w = uni_cols[t];
             if (!w) break;
             const int key0 = t * 64 + __builtin_ctzll(w);
-            uint64_t all = key0 + KT <= L ? ~0ull : 0ull;
-            for (int r = 0; r < rows; ++r) all &= window(bits.data() + (size_t)r * nw, nw, key0);
+            const uint64_t all = key0 + KT <= L ? window(all_cols.data(), nw, key0) : 0ull;
             items.push_back(key0);
             if (all == ~0ull) {
                 items.push_back(-1);
             } else {
-                items.push_back((int32_t)(masks.size() / RB));
-                for (int r = 0; r < RB; ++r) masks.push_back(r < rows ? window(bits.data() + (size_t)r * nw, nw, key0) : 0ull);
+                uint64_t m[RB];
+                uint64_t hsh = 0x9e3779b97f4a7c15ull;
+                for (int r = 0; r < RB; ++r) {
+                    m[r] = r < rows ? window(bits.data() + (size_t)r * nw, nw, key0) : 0ull;
+                    hsh = (hsh ^ m[r]) * 0xff51afd7ed558ccdull;
+                    hsh ^= hsh >> 29;
+                }
+                int32_t found = -1;
+                auto at = mask_of.find(hsh);
+                if (at != mask_of.end())
+                    for (int32_t i = at->second; i >= 0 && found < 0; i = next_same[i])
+                        if (!std::memcmp(masks.data() + (size_t)i * RB, m, sizeof(m))) found = i;
+                if (found < 0) {
+                    found = (int32_t)(masks.size() / RB);
+                    masks.insert(masks.end(), m, m + RB);
+                    next_same.push_back(at != mask_of.end() ? at->second : -1);
+                    mask_of[hsh] = found;
+                }
+                items.push_back(found);
             }
             c = key0 + KT;
         }
@@ -239,6 +265,7 @@ int emit(int L, std::vector<int> cuts, const FillFn& fill, int max_items_per_uni
         for (int32_t t : tw) {  // leave the buffers zero for the next block
             for (int r = 0; r < rows; ++r) bits[(size_t)r * nw + t] = 0ull;
             uni_cols[t] = 0ull;
+            all_cols[t] = 0ull;
             touched[t] = 0;
         }
     }
@@ -369,23 +396,58 @@ extern "C" int sdag_desc_build(int L, int sys_user_len, int n_docs, const int32_
         if (n_docs > 0 && nbr_off[n_docs] > 0 && !nbr_idx) return fail(SDAG_ERR_ARG, "nbr_idx is NULL");
     }
     const int nkt = (L + SDAG_KV_TILE - 1) / SDAG_KV_TILE;
-    auto fill = [&](int r0, int rows, uint64_t* bits, uint8_t* touched) {
-        for (int i = r0; i < r0 + rows; ++i) {
-            uint64_t* row = bits + (size_t)(i - r0) * nkt;
-            if (i < sys_user_len || i >= qa_start) set_range(row, touched, 0, i + 1);  // SDAG.py:107-108, 124-125
-            for (int d = 0; d < n_docs; ++d) {
-                const int s = spans[2 * d], e = spans[2 * d + 1];
-                if (i < s || i >= e) continue;
-                if (sys_user_len > 0) set_range(row, touched, 0, sys_user_len);  // SDAG.py:115
-                set_range(row, touched, s, i + 1);                               // SDAG.py:116
-                if (nbr_off) {
-                    for (int t = nbr_off[d]; t < nbr_off[d + 1]; ++t) {  // SDAG.py:118-122
-                        const int nb = nbr_idx[t];
-                        if (nb < 0 || nb >= n_docs) continue;
-                        const int ns = spans[2 * nb], ne = spans[2 * nb + 1];
-                        if (ne > ns) set_range(row, touched, ns, ne);
-                    }
+    auto fill_row = [&](int i, uint64_t* row, uint8_t* touched) {
+        if (i < sys_user_len || i >= qa_start) set_range(row, touched, 0, i + 1);  // SDAG.py:107-108, 124-125
+        for (int d = 0; d < n_docs; ++d) {
+            const int s = spans[2 * d], e = spans[2 * d + 1];
+            if (i < s || i >= e) continue;
+            if (sys_user_len > 0) set_range(row, touched, 0, sys_user_len);  // SDAG.py:115
+            set_range(row, touched, s, i + 1);                               // SDAG.py:116
+            if (nbr_off) {
+                for (int t = nbr_off[d]; t < nbr_off[d + 1]; ++t) {  // SDAG.py:118-122
+                    const int nb = nbr_idx[t];
+                    if (nb < 0 || nb >= n_docs) continue;
+                    const int ns = spans[2 * nb], ne = spans[2 * nb + 1];
+                    if (ne > ns) set_range(row, touched, ns, ne);
                 }
+            }
+        }
+    };
+    // which of the row's conditions above hold: bit 0 the causal prefix, bit 1 + (d % 62) inside document d (documents
+    // beyond 62 share bits: equal signatures of two rows then do not prove equal conditions, and are not taken to)
+    auto signature = [&](int i) {
+        uint64_t sg = (i < sys_user_len || i >= qa_start) ? 1ull : 0ull;
+        for (int d = 0; d < n_docs; ++d)
+            if (i >= spans[2 * d] && i < spans[2 * d + 1]) sg |= 2ull << (d % 62);
+        return sg;
+    };
+    std::vector<int32_t> words;  // the words the block's rows have bits in
+    auto fill = [&](int r0, int rows, uint64_t* bits, uint8_t* touched) {
+        // The rows of a block lie in one segment of the prompt (the cuts below), so the same conditions hold for all of
+        // them and row i + 1 allows what row i allows plus key i + 1: the first row is built from the ranges, every
+        // further one is its predecessor's words and one more bit.  (Rows that do not share the first row's conditions
+        // -- a caller's cuts would have to differ from those below -- are built from the ranges one by one.)
+        fill_row(r0, bits, touched);
+        if (rows == 1) return;
+        const uint64_t sg = signature(r0);
+        if (n_docs > 62 || signature(r0 + rows - 1) != sg) {
+            for (int i = r0 + 1; i < r0 + rows; ++i) fill_row(i, bits + (size_t)(i - r0) * nkt, touched);
+            return;
+        }
+        words.clear();
+        for (int t = 0; t < nkt; ++t)
+            if (touched[t]) words.push_back(t);
+        for (int i = r0 + 1; i < r0 + rows; ++i) {
+            uint64_t* row = bits + (size_t)(i - r0) * nkt;
+            const uint64_t* prev = row - nkt;
+            for (int32_t t : words) row[t] = prev[t];
+            if (sg) {  // (no condition holds: the rows allow nothing)
+                const int t = i >> 6;
+                if (!touched[t]) {
+                    touched[t] = 1;
+                    words.push_back(t);
+                }
+                row[t] |= 1ull << (i & 63);
             }
         }
     };
@@ -472,6 +534,46 @@ extern "C" int sdag_batch_build(const int32_t* const* descs, int B, int n_stream
                 if (descs[c] == descs[b]) { desc_off[b] = desc_off[c]; break; }
         }
     }
+    // The lane masks the steps point at: ONE pool for the batch, every distinct mask once.  Prompts of like documents
+    // share most of their masks (tiles follow the documents, so a document's staircase looks the same in every prompt):
+    // the workgroups of a compute unit, busy with several sequences at a time, then pull a few KiB through the scalar
+    // cache instead of every sequence's own copies.
+    std::vector<std::vector<int32_t>> lmask_at((size_t)B);
+    std::vector<const int32_t*> pool;  // source of every pooled mask (64 words)
+    {
+        std::unordered_map<uint64_t, std::vector<int32_t>> seen;  // hash -> pool indices
+        off = align_up(off, 16);
+        for (int b = 0; b < B; ++b) {
+            const int32_t* d = descs[b];
+            int first = 0;
+            while (descs[first] != d) ++first;
+            if (first < b) { lmask_at[b] = lmask_at[first]; continue; }
+            const int32_t* lm = d + d[H_OFF_LMASKS];
+            lmask_at[b].resize((size_t)d[H_NMASKS]);
+            for (int m = 0; m < d[H_NMASKS]; ++m) {
+                const int32_t* src = lm + (size_t)m * 64;
+                uint64_t hsh = 0x9e3779b97f4a7c15ull;
+                for (int i = 0; i < 32; ++i) {
+                    uint64_t w;
+                    std::memcpy(&w, src + 2 * i, 8);
+                    hsh = (hsh ^ w) * 0xff51afd7ed558ccdull;
+                    hsh ^= hsh >> 29;
+                }
+                int32_t found = -1;
+                std::vector<int32_t>& cands = seen[hsh];
+                for (int32_t c : cands)
+                    if (!std::memcmp(pool[(size_t)c], src, 256)) { found = c; break; }
+                if (found < 0) {
+                    found = (int32_t)pool.size();
+                    pool.push_back(src);
+                    cands.push_back(found);
+                }
+                lmask_at[b][(size_t)m] = (int32_t)(off + (int64_t)found * 64);
+            }
+        }
+    }
+    const int64_t off_pool = off;
+    off += (int64_t)pool.size() * 64;
     const int64_t total = align_up(off, 16);
     if (n_words) *n_words = total;
     if (total > 0x7fffffff || n_slots > 0x7fffffff) return fail(SDAG_ERR_ARG, "batch table too large");
@@ -487,8 +589,10 @@ extern "C" int sdag_batch_build(const int32_t* const* descs, int B, int n_stream
             for (int64_t w = end; w < desc_off[b]; ++w) out[w] = 0;
             end = (int64_t)desc_off[b] + u[H_OFF_STEPS];
         }
-        for (int64_t w = end; w < total; ++w) out[w] = 0;
+        for (int64_t w = end; w < off_pool; ++w) out[w] = 0;
+        for (int64_t w = off_pool + (int64_t)pool.size() * 64; w < total; ++w) out[w] = 0;
     }
+    for (size_t i = 0; i < pool.size(); ++i) std::memcpy(out + off_pool + (int64_t)i * 64, pool[i], 256);
     out[BT_MAGIC] = BATCH_MAGIC;
     out[BT_VERSION] = BATCH_VERSION;
     out[BT_B] = B;
@@ -524,7 +628,7 @@ extern "C" int sdag_batch_build(const int32_t* const* descs, int B, int n_stream
         const int32_t* u = d + d[H_OFF_UNITS];
         for (int i = 0; i < d[H_NUNITS]; ++i, u += UNIT_WORDS)
             su.push_back({b, u[7], u[1], u[2], u[3] < 0 ? -1 : slot_base[b] + u[3], u[4], d[H_L], d + d[H_OFF_ITEMS],
-                          (int64_t)desc_off[b] + d[H_OFF_LMASKS]});
+                          (int64_t)desc_off[b] + d[H_OFF_LMASKS], lmask_at[b].data()});
     }
     // A batch with plenty of units per stream: the units of every sequence are cut in two by the keys they end at
     // (the first documents | the last documents and the rows that see everything), at equal cost, and each part goes

@@ -113,7 +113,11 @@ def check_schedule(words, steps_off, streams_off, n_streams, units_of, base_of=N
                 if mi < 0:
                     assert st[1] == 0
                 else:
-                    assert st[1] == doff + d[H["OFF_LMASKS"]] + 64 * mi and st[1] % 16 == 0
+                    # the step's lane mask: 64 words at a 64-byte boundary of the table that equal lane mask mi of the
+                    # sequence (its own copy in a single descriptor; one pooled copy per distinct mask in a batch)
+                    assert st[1] % 16 == 0 and 0 < st[1] and st[1] + 64 <= len(w)
+                    own = d[H["OFF_LMASKS"]] + 64 * mi
+                    assert np.array_equal(w[st[1]: st[1] + 64], d[own: own + 64])
             i += n
     return seen, np.diff(so)
 
