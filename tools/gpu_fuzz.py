@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU (diagnostic): the search against the C oracle (ids and score bits) over random
-corpus sizes, dimensions, query counts and k, and the attention kernels against the fp32 oracle over random layouts,
-head counts, unit lengths, stream counts and batches.  usage: tools/gpu_fuzz.py [cases] [seed]"""
+corpus sizes, dimensions, query counts and k, the attention kernels against the fp32 oracle over random layouts,
+head counts, unit lengths, stream counts and batches, and the decode kernel (plain, right-padded, preallocated cache)
+against an fp32 softmax on the same inputs.  usage: tools/gpu_fuzz.py [cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sparse-document-attention-rag-_amd")); sys.path.insert(0, ROOT)
@@ -73,5 +74,44 @@ for c in range(cases):
         bad += 1
         print("ATTENTION MISMATCH", dict(L=L, sys=sys_len, spans=spans, qa=qa, nbr=nbr, Hq=Hq, Hkv=Hkv, B=B, T=T, ns=ns, e1=e1, e2=e2, mask=m), flush=True)
     print(f"attention {c}: L={L} docs={n_docs} Hq={Hq} Hkv={Hkv} B={B} T={T} streams={ns} err {e1:.1e} {e2:.1e}", flush=True)
+# decode attention: random batch, head counts, cache lengths, right padding, preallocated caches with NaN tails
+for c in range(cases):
+    B = int(rng.choice([1, 2, 5, 32, 40])); Hkv = int(rng.choice([1, 2, 8])); G = int(rng.choice([1, 2, 4, 5, 7])); Hq = Hkv * G
+    S = int(rng.choice([1, 2, 63, 64, 65, 200, 1000, 3100, 4500]))
+    if B >= 32 and S > 1000:
+        S = 1000
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    q = torch.randn(B, 1, Hq, 128, generator=g).to(torch.bfloat16).transpose(1, 2)
+    kk = torch.randn(B, S, Hkv, 128, generator=g).to(torch.bfloat16).transpose(1, 2)
+    v = torch.randn(B, S, Hkv, 128, generator=g).to(torch.bfloat16).transpose(1, 2)
+    mode = int(rng.integers(0, 3))  # 0 plain, 1 right-padded, 2 preallocated (+ padded)
+    live = torch.ones(B, S, dtype=torch.bool)
+    valid = pad_end = n_rows = None
+    kd, vd = kk.clone(), v.clone()
+    if mode >= 1 and S > 2:
+        pad_end = int(rng.integers(1, S + 1))
+        vl = rng.integers(1, pad_end + 1, B)
+        for b in range(B):
+            live[b, vl[b]:pad_end] = False
+            vd[b, :, vl[b]:pad_end] = float("nan")      # padding rows are never read as data
+        valid = torch.tensor(vl, dtype=torch.int32, device=dev)
+    if mode == 2 and S > 2:
+        n = int(rng.integers(max(1, pad_end or 1), S + 1))
+        live[:, n:] = False
+        kd[:, :, n:] = float("nan"); vd[:, :, n:] = float("nan")
+        n_rows = torch.tensor([n], dtype=torch.int32, device=dev)
+    if not live.any(dim=1).all():
+        continue
+    o = sdag_amd.decode_attention(q.to(dev), kd.to(dev), vd.to(dev), out_dtype=torch.float32, valid_len=valid,
+                                  pad_end=pad_end or 0, n_rows=n_rows).cpu()
+    qf, kf, vf = q.float(), kk.float().repeat_interleave(G, 1), v.float().repeat_interleave(G, 1)
+    sc = torch.einsum("bhqd,bhsd->bhqs", qf, kf) * 128 ** -0.5
+    sc = sc.masked_fill(~live[:, None, None, :], float("-inf"))
+    ref = torch.einsum("bhqs,bhsd->bhqd", torch.softmax(sc, -1), vf).transpose(1, 2)
+    err = float(((o - ref).abs().amax(dim=(0, 1, 3)) / ref.abs().amax(dim=(0, 1, 3)).clamp_min(1e-30)).max())
+    if not err <= 1e-3:
+        bad += 1
+        print("DECODE MISMATCH", dict(B=B, Hq=Hq, Hkv=Hkv, S=S, mode=mode, pad_end=pad_end, err=err), flush=True)
+    print(f"decode {c}: B={B} Hq={Hq} Hkv={Hkv} S={S} mode={mode} err {err:.1e}", flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
