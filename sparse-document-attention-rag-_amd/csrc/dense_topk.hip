@@ -1031,10 +1031,17 @@ __device__ __forceinline__ unsigned block_kth_largest(const unsigned (&key)[8], 
 // need their exact score.  Otherwise (fewer than k reach s_m, more than RS2_HI do, the list overflowed or the scan
 // dropped survivors) the flag makes the exact scan answer.  Without a sample statistic the threshold is -FLT_MAX, the
 // list is the whole corpus and every entry is scored.
-// grid (RS_G, queries): every block finds the line on its own (the list's scores at or above s_m, up to RS2_HI of
-// them), takes the entries at list positions g, g + RS_G, ... that reach it, scores them in chunks of RS_CB, ranks them
-// and writes its best k as partial list g of the query, in the layout the merge kernel reads.
-constexpr int RS2_MAX = 256;   // list entries one block looks at: list capacity / RS_G
+// grid (RS2_G, queries): every block finds the line on its own (the list's scores at or above s_m, up to RS2_HI of
+// them), takes the entries at list positions g, g + RS2_G, ... that reach it, scores them in chunks of RS_CB, ranks them
+// and writes its best k as partial list g of the query, in the layout the merge kernel reads.  (Four blocks per query:
+// finding the line costs a block some thirty barriers whatever it scores afterwards, and a 256-query pass with sixteen
+// blocks per query is 4,096 blocks that each repeat it.)
+#ifndef SDAG_RS2_G
+#define SDAG_RS2_G 4
+#endif
+constexpr int RS2_G = SDAG_RS2_G;   // blocks per query
+constexpr int THR_CAP_ = 4096;      // candidates per query the global lists hold
+constexpr int RS2_MAX = THR_CAP_ / RS2_G;   // list entries one block looks at
 constexpr int RS2_HI = 2048;   // scores at or above s_m a block can select among (8 per thread)
 __global__ __launch_bounds__(256) void rescore_cand_kernel(const float* __restrict__ Q, const float* __restrict__ C, int d, int k,
                                                            const ThrArgs ta, int q_stride, float* __restrict__ blk_s,
@@ -1083,9 +1090,9 @@ __global__ __launch_bounds__(256) void rescore_cand_kernel(const float* __restri
     }
     if (bad && g == 0 && tid == 0) atomicOr(ta.flag, 1);
     // ---- this block's entries at or above the line
-    if (g + tid * RS_G < n_all && tid < RS2_MAX && !(bad && sampled)) {
-        if (ls[g + tid * RS_G] >= line) sel[atomicAdd(&n_sel_s, 1)] = li[g + tid * RS_G];
-    }
+    if (!(bad && sampled))
+        for (int e = g + tid * RS2_G; e < n_all; e += 256 * RS2_G)
+            if (ls[e] >= line) sel[atomicAdd(&n_sel_s, 1)] = li[e];
     __syncthreads();
     const int n_mine = n_sel_s;
     constexpr int PER_ROW = RS_DC / 4, PIECES = RS_CB * PER_ROW / 256;
@@ -1356,7 +1363,7 @@ namespace {
 // sub-passes of up to 128.
 constexpr int THR_STEP = 32;            // the pilot scans one 128-row tile in THR_STEP
 constexpr int THR_MIN_TILES = 8;        // ... and needs at least this many (else: the list scan)
-constexpr int THR_CAP = RS_G * RS2_MAX; // candidates per query the global lists hold
+constexpr int THR_CAP = THR_CAP_;
 // Entries the pilot keeps per query: the number of rows of the whole corpus at or above the sample's m-th best score is
 // about THR_STEP times a Gamma(m) variate; it has to reach k for the candidate list to be vouched for, and with
 // m = 4 + ceil(k / 6) it fails to with a probability of some 1e-5 per query (k = 10: m = 6, 190 such rows expected).
@@ -1492,7 +1499,7 @@ extern "C" int sdag_dense_topk2(const float* Q, int nq, const float* C, const vo
                                (int64_t)0, const_cast<float*>(ta.pilot_s), const_cast<int64_t*>(ta.pilot_i), (const int*)nullptr);
             SDAG_HIP_CHECK(hipGetLastError());
             if (int rc = launch_thr_scan<MODE_THR>(nqb, w.main.n_wg, st, (const void*)q16p, nqt, C16, N, d, w.main.rows_per_wg, 1, ta)) return rc;
-            hipLaunchKernelGGL(rescore_cand_kernel, dim3(RS_G, nqt), dim3(256), 0, st, Q + (int64_t)q0 * d, C, d, k, ta, qtw, rs_s, rs_i);
+            hipLaunchKernelGGL(rescore_cand_kernel, dim3(RS2_G, nqt), dim3(256), 0, st, Q + (int64_t)q0 * d, C, d, k, ta, qtw, rs_s, rs_i);
             SDAG_HIP_CHECK(hipGetLastError());
         } else {
             if (N > 0)
@@ -1503,7 +1510,7 @@ extern "C" int sdag_dense_topk2(const float* Q, int nq, const float* C, const vo
                                N > 0 ? w.main.n_wg : 0, qtw, eps + q0, rs_s, rs_i, flag);
             SDAG_HIP_CHECK(hipGetLastError());
         }
-        hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, rs_s, rs_i, RS_G, nqt, qtw, k, id_base, os, oi,
+        hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(nqt), dim3(MRG_THREADS), 0, st, rs_s, rs_i, w.thr ? RS2_G : RS_G, nqt, qtw, k, id_base, os, oi,
                            (const int*)nullptr);
         SDAG_HIP_CHECK(hipGetLastError());
         if (N > 0 && !SDAG_SCAN_EXP) {
